@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the OverlapNet hot path on MI355X -- BASELINE.json metric: scan-pairs/s on 64x900 range images.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pool P] [--channels C]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one loop-closure query the way the reference's `Infer.infer_multiple` runs it
+(src/two_heads/infer.py:162-203): the leg over the query scan (1 scan, 64x900xC, already in HBM) plus BOTH
+heads of that query against the P candidate feature volumes cached in HBM ("warm" sweep: candidates' legs ran
+when they were the current frame, infer.py:184-185).  N = 1, P = 1024, C = 4 is BASELINE.json configs[1]
+("batched 1-vs-1024 pairs, 64x900 depth+normals").  With N > 1 every rank holds its own P candidates
+(weak scaling, 1-vs-N*P), the only collective is the per-step gather of (overlap, yaw) to rank 0.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from overlapnet_amd import distributed as D  # noqa: E402
+from overlapnet_amd import synthetic as S  # noqa: E402
+from overlapnet_amd.engine import OvnEngine  # noqa: E402
+
+# algorithmic work of the dominant kernel (fused DeltaLayer + c_conv1 + c_conv2), SURVEY.md section 8a row a7:
+#   c_conv1 8640 x 1920 x 64 and c_conv2 576 x 960 x 128 multiply-adds per pair, FLOP = 2 * MAC
+DELTA_C12_FLOP_PER_PAIR = 2 * (8640 * 1920 * 64 + 576 * 960 * 128)
+HEAD_FLOP_PER_PAIR = 2_550_646_784          # whole Delta head
+CORR_FLOP_PER_PAIR = 33_177_600
+CAND_BYTES_PER_PAIR = 184_320 + 8           # candidate feature volume read once + (overlap, yaw) written
+PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def cpu_baseline(channels: int, pool: int):
+    """The CPU restatement oracle (PyTorch-CPU fp32, structured like the reference: leg model, then head
+    model in batches of 16 with the 360x360x128 Delta tensor materialised) timed on this host's cores on
+    a bounded sample: 1 leg + 32 pairs, extrapolated to the 1-leg + `pool`-pairs step."""
+    from oracle import overlapnet_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = S.make_test_weights(channels, seed=0)
+    imgs = S.candidate_images(3, channels, seed=5)
+    O.leg_forward(imgs[:1], w, S.REFERENCE_MODEL_CFG, np.float32)  # warm the thread pool
+    t0 = time.perf_counter()
+    fv = O.leg_forward(imgs, w, S.REFERENCE_MODEL_CFG, np.float32)
+    t_leg = (time.perf_counter() - t0) / imgs.shape[0]
+    n_pairs = 32
+    li = np.arange(n_pairs) % 3
+    ri = np.zeros(n_pairs, int)
+    t0 = time.perf_counter()
+    for b in range(0, n_pairs, 16):
+        O.heads_forward(fv[li[b:b + 16]], fv[ri[b:b + 16]], w, dtype=np.float32)
+    t_pair = (time.perf_counter() - t0) / n_pairs
+    step_s = t_leg + pool * t_pair
+    return {"value": pool / step_s, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "oracle fp32 (PyTorch-CPU): 3 legs + 32 head pairs in batches of 16 timed, extrapolated to "
+                      "1 leg + %d pairs; leg %.3f s/scan, heads %.4f s/pair" % (pool, t_leg, t_pair)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pool", type=int, default=1024, help="candidate feature volumes resident per GPU")
+    ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against the fp64 oracle (untimed)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    C, P = args.channels, args.pool
+    eng = OvnEngine(64, 900, C, device=local_rank)
+    w = S.make_test_weights(C, seed=0)
+    eng.load_weights(w, S.REFERENCE_MODEL_CFG)
+
+    # ---- untimed setup: candidate pool -> feature volumes resident in HBM (each rank its own pool) ----
+    fx = S.load_fixture_images()
+    cands = torch.empty((P, 360, 128), dtype=torch.float32, device=dev)
+    chunk = 128
+    for s in range(0, P, chunk):
+        n = min(chunk, P - s)
+        imgs = S.candidate_images(n, C, seed=1234 + 7919 * rank + s, fixture=fx)
+        # distinct shifts across chunks / ranks
+        imgs = np.roll(imgs, (s * 37 + rank * 11) % 900, axis=2)
+        eng.leg(torch.from_numpy(np.ascontiguousarray(imgs)).to(dev), out=cands[s:s + n])
+    query_img = torch.from_numpy(S.stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], S.flags_of(C))[None]).to(dev)
+    query_fv = torch.empty((1, 360, 128), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        eng.leg(query_img, out=query_fv)
+        r = eng.heads(cands, query_fv)
+        if world > 1:
+            return D.gather_scores(r["overlap"], r["yaw"], P * world)
+        return r["overlap"], r["yaw"]
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.profile_begin()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = P * world * args.steps
+        ms_step = 1e3 * elapsed / args.steps
+        d_ms, d_n = prof["delta_c12"]
+        avg_ms = d_ms / max(d_n, 1)
+        achieved = DELTA_C12_FLOP_PER_PAIR * P / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
+        kernels = {k: {"ms_per_launch": (v[0] / v[1] if v[1] else None), "launches": v[1]} for k, v in prof.items() if v[1]}
+        out = {
+            "metric": "scan-pairs/s (64x900 range images)", "value": pairs / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
+                                   "64x900x%d range images" % (P, P, C),
+                       "pairs_per_step": P * world, "channels": C, "weights": "seeded synthetic (no trained weights ship)",
+                       "collective": "gather of (overlap,yaw) to rank 0 per step" if world > 1 else "none"},
+            "roofline": {"bound": "mfma", "kernel": "delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)",
+                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * P, "avg_launch_ms": avg_ms},
+            "kernels": kernels,
+            "head_hbm_gbps_algorithmic": (P * world * args.steps / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
+        }
+        # accuracy part of the metric ("overlap MAE vs ref"): untimed check against the fp64 oracle
+        if args.accuracy_pairs > 0:
+            from oracle import overlapnet_oracle as O
+            k = min(args.accuracy_pairs, P)
+            ov = res[0][:k].float().cpu().numpy()
+            yw = res[1][:k].cpu().numpy()
+            fl = cands[:k].cpu().numpy().reshape(k, 1, 360, 128).astype(np.float64)
+            fr = np.repeat(query_fv.cpu().numpy().reshape(1, 1, 360, 128).astype(np.float64), k, axis=0)
+            o_ov, o_yaw, _, _ = O.heads_forward(fl, fr, w)
+            out["overlap_mae_vs_oracle"] = float(np.mean(np.abs(ov - o_ov)))
+            out["overlap_maxerr_vs_oracle"] = float(np.max(np.abs(ov - o_ov)))
+            out["yaw_exact_rate"] = float(np.mean(yw == o_yaw))
+            out["accuracy_pairs"] = int(k)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(C, P)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,137 @@
+/*
+ * ovn_hip.h -- C ABI of libovn_hip.so, the MI355X (gfx950) OverlapNet inference hot path.
+ *
+ * The reference (PRBonn/OverlapNet) has no FFI layer of its own: its hot path is reached through the
+ * Python class `Infer` (src/two_heads/infer.py:22) which hands everything to Keras/TensorFlow.  These
+ * entry points are what a binding for that path has to reach; each one names the reference code it
+ * replaces.  The Python host (`overlapnet_amd/infer.py`) calls them through ctypes.
+ *
+ * Conventions
+ *   - every pointer marked "dev" is a DEVICE pointer (HIP memory owned by the caller, e.g. a torch
+ *     tensor's data_ptr()); the library never takes ownership and never frees caller memory;
+ *   - all tensors are float32, channels-last (NHWC), densely packed;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); every call only
+ *     ENQUEUES work on it, nothing synchronises unless stated;
+ *   - return value 0 = success, non-zero = error, message via ovn_last_error() (thread-local);
+ *   - one context per GPU per process; calls on one context are not re-entrant (the reference object
+ *     is not thread-safe either: mutable feature cache, infer.py:114,185).
+ */
+#ifndef OVN_HIP_H
+#define OVN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ovn_ctx ovn_ctx;
+
+#define OVN_OK 0
+#define OVN_ERR_ARG 1      /* bad argument / unsupported shape */
+#define OVN_ERR_HIP 2      /* HIP runtime error                */
+#define OVN_ERR_STATE 3    /* call order (weights missing ...)  */
+
+/* ABI version of this header; bumped on any signature change. */
+#define OVN_ABI_VERSION 1
+int ovn_abi_version(void);
+
+/* Last error message of the calling thread ("" if none). */
+const char* ovn_last_error(void);
+
+/* Create / destroy a context bound to HIP device `device_id` for leg inputs of in_h x in_w x in_c
+ * (64 x 900 x C in the reference, infer.py:76-82).  Replaces the model construction of
+ * Infer.__init__ (infer.py:86-111). */
+int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out);
+int ovn_destroy(ovn_ctx* ctx);
+
+/* Register one convolution layer of the leg, in network order (generateNet.py:161-214: s_conv1 ...
+ * s_conv10).  kernel_dev: Keras layout (kh, kw, cin, cout); bias_dev: (cout).  The library keeps its
+ * own re-tiled copy (MFMA fragment order), so the caller may release its buffers after the call
+ * returns (the call synchronises `stream`).  All leg layers are valid-padded + bias + ReLU.
+ * Replaces `leg.load_weights(file, by_name=True)` (infer.py:119). */
+int ovn_add_leg_layer(ovn_ctx* ctx, const char* name, const float* kernel_dev, const float* bias_dev,
+                      int kh, int kw, int cin, int cout, int stride_h, int stride_w, void* stream);
+
+/* Register the Delta-head weights (generateNet.py:96-114): c_conv1 (1,15,128,64) linear,
+ * c_conv2 (15,1,64,128) ReLU, c_conv3 (3,3,128,256) ReLU, overlap_output Dense (123904,1) sigmoid.
+ * Same ownership rule as above.  Replaces `head.load_weights(...)` (infer.py:120). */
+int ovn_set_head_weights(ovn_ctx* ctx, const float* c1_kernel_dev, const float* c1_bias_dev,
+                         const float* c2_kernel_dev, const float* c2_bias_dev,
+                         const float* c3_kernel_dev, const float* c3_bias_dev,
+                         const float* dense_kernel_dev, const float* dense_bias_dev, void* stream);
+
+/* Validate the registered leg chain: output must be 1 x feat_w x 128 (1 x 360 x 128 in the reference).
+ * Writes the leg output width to *feat_w. */
+int ovn_finalize(ovn_ctx* ctx, int* feat_w);
+
+/* Leg: images_dev (n, in_h, in_w, in_c) -> features_dev (n, feat_w, 128).
+ * Replaces `leg.predict_generator` in Infer.create_feature_volumes (infer.py:262-265). */
+int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_dev, void* stream);
+
+/* Both heads on n pairs.  Pair p uses l = feats_l_dev[lidx[p]] and r = feats_r_dev[ridx[p]]
+ * (each feature volume feat_w x 128 floats); lidx_dev == NULL means lidx[p] = p, ridx_dev == NULL means
+ * ridx[p] = 0 (the 1-vs-N sweep of Infer.infer_multiple, infer.py:188-190: l = candidate, r = query).
+ * Outputs (any may be NULL except overlap/yaw):
+ *   overlap_dev (n) f32  = sigmoid(logit)            (generateNet.py:114)
+ *   yaw_dev     (n) i32  = 180 - argmax_k corr[k]    (infer.py:158; first maximum wins)
+ *   logit_dev   (n) f32  pre-sigmoid value
+ *   corr_dev    (n, feat_w) f32 orientation_output   (generateNet.py:352)
+ * Replaces `head.predict_generator` + post-processing (infer.py:155-158,194-198,229-233) and the pair
+ * gather of ImagePairOverlapSequenceFeatureVolume.__getitem__ (:43-47). */
+int ovn_heads(ovn_ctx* ctx, const float* feats_l_dev, const int32_t* lidx_dev, const float* feats_r_dev,
+              const int32_t* ridx_dev, int64_t n, float* overlap_dev, int32_t* yaw_dev, float* logit_dev,
+              float* corr_dev, void* stream);
+
+/* Correlation (yaw) head alone (NormalizedCorrelation2D.py:43-109 with normalize='none'); same
+ * indexing convention as ovn_heads. */
+int ovn_corr_head(ovn_ctx* ctx, const float* feats_l_dev, const int32_t* lidx_dev, const float* feats_r_dev,
+                  const int32_t* ridx_dev, int64_t n, int32_t* yaw_dev, float* corr_dev, void* stream);
+
+/* Spherical projection + normals for a batch of scans (src/utils/utils.py:59-134 range_projection and
+ * :137-186 gen_normal_map; the drivers gen_depth_data.py:24-46 etc. loop over files and call these).
+ *   points_dev   concatenated (x,y,z,intensity) float32 points of all scans
+ *   offsets_dev  (n_scans+1) int64 point offsets into points_dev (scan s = [offsets[s], offsets[s+1]))
+ * Outputs, each may be NULL: range (n,H,W), vertex (n,H,W,4), intensity (n,H,W), idx (n,H,W) int32
+ * (index among the points that pass the range filter, utils.py:117-118), normal (n,H,W,3), and
+ * stacked (n,H,W,C) = the leg input assembled in the reference's channel order depth|normals|intensity
+ * (ImagePairOverlapOrientationSequence.py:143-207) according to the use_* flags.  Empty pixels = -1.
+ * max_points_per_scan bounds the per-scan launch (>= the largest scan). */
+int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_dev, int n_scans,
+                int64_t max_points_per_scan, int proj_h, int proj_w, double fov_up_deg, double fov_down_deg,
+                double max_range, float* range_dev, float* vertex_dev, float* intensity_dev,
+                int32_t* idx_dev, float* normal_dev, float* stacked_dev, int use_depth, int use_normals,
+                int use_intensity, void* stream);
+
+/* Normal map alone from given range (n,H,W) and vertex (n,H,W,4) images -> normal (n,H,W,3)
+ * (src/utils/utils.py:137-186 gen_normal_map). */
+int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,
+                float* normal_dev, void* stream);
+
+/* Per-kernel-class timing with HIP events recorded on the launch stream, for bench.py's roofline line.
+ * Between begin and end every kernel group launched through this context is bracketed by an event
+ * pair; ovn_profile_end waits for them and returns, per class, the summed milliseconds and the number
+ * of bracketed launches.  Classes: 0 leg convolutions (one entry per layer launch), 1 correlation head,
+ * 2 fused Delta kernel (DeltaLayer+c_conv1+c_conv2), 3 c_conv3, 4 dense+sigmoid, 5 projection. Arrays of 8. */
+int ovn_profile_begin(ovn_ctx* ctx);
+int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind);
+
+/* Test hook: run registered leg layer `layer` alone on in_dev (nb,h,w,cin) -> out_dev (nb,oh,ow,cout). */
+int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, int w, float* out_dev, void* stream);
+
+/* Test hook: copy the c_conv2 (n,24,24,128) and c_conv3 (n,22,22,256) activations that the most recent
+ * ovn_heads call left in scratch (its first chunk, n <= min(pairs, 2048)); either output may be NULL.
+ * (generateNet.py:102-110 intermediates; the reference exposes them as Keras layer outputs.) */
+int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream);
+
+/* Device scratch currently held by the context, in bytes (grows on demand, freed by ovn_destroy). */
+int64_t ovn_workspace_bytes(ovn_ctx* ctx);
+
+/* Self-test of the MFMA fragment layouts this library relies on (runs a few tiny kernels on the
+ * context's device and compares with a host matmul).  0 = all layouts as assumed. */
+int ovn_selftest(ovn_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OVN_HIP_H */

@@ -1,0 +1,91 @@
+"""ctypes binding of libovn_hip.so (C ABI declared in include/ovn_hip.h).
+
+There is NO fallback: if the shared library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libovn_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+ABI_VERSION = 1
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_vp = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/ovn_hip.h one to one
+SIGNATURES = {
+    "ovn_abi_version": (C.c_int, []),
+    "ovn_last_error": (C.c_char_p, []),
+    "ovn_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "ovn_destroy": (C.c_int, [_vp]),
+    "ovn_add_leg_layer": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "ovn_set_head_weights": (C.c_int, [_vp] + [_vp] * 8 + [_vp]),
+    "ovn_finalize": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "ovn_leg": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
+    "ovn_heads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "ovn_corr_head": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "ovn_project": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
+                              C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
+    "ovn_normals": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "ovn_profile_begin": (C.c_int, [_vp]),
+    "ovn_profile_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "ovn_debug_conv": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "ovn_debug_head_activations": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "ovn_workspace_bytes": (C.c_int64, [_vp]),
+    "ovn_selftest": (C.c_int, [_vp]),
+}
+
+
+class OvnError(Exception):
+    pass
+
+
+def build(force: bool = False, quiet: bool = True) -> str:
+    """Compile libovn_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC_DIR, "clean"], check=True, capture_output=quiet)
+    r = subprocess.run(["make", "-C", CSRC_DIR, "-j8"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise OvnError("building libovn_hip.so failed:\n" + r.stdout + r.stderr)
+    if not os.path.isfile(LIB_PATH):
+        raise OvnError("make succeeded but %s is missing" % LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the shared library and bind every symbol of the header. Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise OvnError("%s not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                       "g.build()'` (or `make -C overlapnet_amd/csrc`). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise OvnError("libovn_hip.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.ovn_abi_version()
+    if v != ABI_VERSION:
+        raise OvnError("libovn_hip.so ABI version %d, Python binding expects %d: rebuild" % (v, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ovn_last_error()
+        raise OvnError("%s failed (code %d): %s" % (what, rc, (msg or b"").decode("utf-8", "replace")))

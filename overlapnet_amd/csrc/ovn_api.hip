@@ -1,0 +1,368 @@
+// extern "C" surface of libovn_hip.so (declared in include/ovn_hip.h) -- argument checking, weight
+// re-tiling, scratch management and the launch sequences.  No torch types anywhere: plain pointers.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ovn_internal.h"
+
+static thread_local char g_err[1024] = "";
+
+void ovn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int ovn_ws_reserve(ovn_ctx* ctx, size_t bytes, hipStream_t stream) {
+  if (bytes <= ctx->ws_bytes) return OVN_OK;
+  if (ctx->ws) {
+    OVN_HIP_CHECK(hipStreamSynchronize(stream));  // earlier launches may still use the old block
+    OVN_HIP_CHECK(hipFree(ctx->ws));
+    ctx->ws = nullptr;
+    ctx->ws_bytes = 0;
+  }
+  const size_t want = bytes + bytes / 8;  // a little headroom so near-equal requests do not thrash
+  OVN_HIP_CHECK(hipMalloc(&ctx->ws, want));
+  ctx->ws_bytes = want;
+  return OVN_OK;
+}
+
+extern "C" {
+
+int ovn_abi_version(void) { return OVN_ABI_VERSION; }
+
+const char* ovn_last_error(void) { return g_err; }
+
+int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
+  OVN_REQUIRE(out != nullptr, OVN_ERR_ARG, "ovn_create: out is NULL");
+  OVN_REQUIRE(in_h > 0 && in_w > 0 && in_c > 0, OVN_ERR_ARG, "ovn_create: bad input shape %dx%dx%d", in_h, in_w, in_c);
+  int ndev = 0;
+  OVN_HIP_CHECK(hipGetDeviceCount(&ndev));
+  OVN_REQUIRE(device_id >= 0 && device_id < ndev, OVN_ERR_ARG, "ovn_create: device %d not present (%d devices)", device_id, ndev);
+  OVN_HIP_CHECK(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  OVN_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
+  OVN_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, OVN_ERR_STATE,
+              "ovn_create: this library is built for gfx950 only, device %d is %s", device_id, prop.gcnArchName);
+  ovn_ctx* c = new ovn_ctx();
+  c->device = device_id;
+  c->in_h = in_h;
+  c->in_w = in_w;
+  c->in_c = in_c;
+  *out = c;
+  return OVN_OK;
+}
+
+int ovn_destroy(ovn_ctx* ctx) {
+  if (!ctx) return OVN_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipDeviceSynchronize();
+  for (auto& l : ctx->leg) ovn_conv_release(&l);
+  ovn_conv_release(&ctx->c2);
+  ovn_conv_release(&ctx->c3);
+  if (ctx->w1p) (void)hipFree(ctx->w1p);
+  if (ctx->b1) (void)hipFree(ctx->b1);
+  if (ctx->wd) (void)hipFree(ctx->wd);
+  if (ctx->bd) (void)hipFree(ctx->bd);
+  if (ctx->ws) (void)hipFree(ctx->ws);
+  delete ctx;
+  return OVN_OK;
+}
+
+int ovn_add_leg_layer(ovn_ctx* ctx, const char* name, const float* kernel_dev, const float* bias_dev, int kh, int kw,
+                      int cin, int cout, int stride_h, int stride_w, void* stream) {
+  OVN_REQUIRE(ctx && name && kernel_dev && bias_dev, OVN_ERR_ARG, "ovn_add_leg_layer: NULL argument");
+  OVN_REQUIRE(kh > 0 && kw > 0 && cin > 0 && cout > 0 && stride_h > 0 && stride_w > 0, OVN_ERR_ARG,
+              "ovn_add_leg_layer(%s): bad geometry", name);
+  OVN_REQUIRE(!ctx->finalized, OVN_ERR_STATE, "ovn_add_leg_layer(%s): context already finalized", name);
+  const int expect_cin = ctx->leg.empty() ? ctx->in_c : ctx->leg.back().cout;
+  OVN_REQUIRE(cin == expect_cin, OVN_ERR_ARG, "ovn_add_leg_layer(%s): cin=%d but previous layer produces %d", name, cin, expect_cin);
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OvnConvLayer L;
+  L.name = name;
+  L.kh = kh;
+  L.kw = kw;
+  L.cin = cin;
+  L.cout = cout;
+  L.sh = stride_h;
+  L.sw = stride_w;
+  L.relu = 1;  // every leg layer is Conv2D(..., activation='relu'), generateNet.py:161-214
+  int rc = ovn_conv_prepare(&L, kernel_dev, bias_dev, (hipStream_t)stream);
+  if (rc) return rc;
+  ctx->leg.push_back(L);
+  return OVN_OK;
+}
+
+int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const float* c2k, const float* c2b,
+                         const float* c3k, const float* c3b, const float* dk, const float* db, void* stream_) {
+  OVN_REQUIRE(ctx && c1k && c1b && c2k && c2b && c3k && c3b && dk && db, OVN_ERR_ARG, "ovn_set_head_weights: NULL argument");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  if (ctx->head_set) {
+    ovn_conv_release(&ctx->c2);
+    ovn_conv_release(&ctx->c3);
+    if (ctx->w1p) (void)hipFree(ctx->w1p);
+    if (ctx->b1) (void)hipFree(ctx->b1);
+    if (ctx->wd) (void)hipFree(ctx->wd);
+    if (ctx->bd) (void)hipFree(ctx->bd);
+    ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
+    ctx->head_set = false;
+  }
+  int rc = ovn_delta_prepare_w1(c1k, &ctx->w1p, stream);
+  if (rc) return rc;
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->b1, OVN_C1_OUT * sizeof(float)));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->b1, c1b, OVN_C1_OUT * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  // c_conv2 (15,1,64,128): as a GEMM operand it is the [960][128] matrix, k = di*64 + o
+  ctx->c2 = OvnConvLayer();
+  ctx->c2.name = "c_conv2";
+  ctx->c2.kh = OVN_S;
+  ctx->c2.kw = 1;
+  ctx->c2.cin = OVN_C1_OUT;
+  ctx->c2.cout = OVN_C2_OUT;
+  ctx->c2.sh = OVN_S;
+  ctx->c2.sw = 1;
+  ctx->c2.relu = 1;
+  rc = ovn_conv_prepare(&ctx->c2, c2k, c2b, stream);
+  if (rc) return rc;
+  ctx->c3 = OvnConvLayer();
+  ctx->c3.name = "c_conv3";
+  ctx->c3.kh = 3;
+  ctx->c3.kw = 3;
+  ctx->c3.cin = OVN_C2_OUT;
+  ctx->c3.cout = OVN_C3_OUT;
+  ctx->c3.sh = 1;
+  ctx->c3.sw = 1;
+  ctx->c3.relu = 1;
+  rc = ovn_conv_prepare(&ctx->c3, c3k, c3b, stream);
+  if (rc) return rc;
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->wd, (size_t)OVN_DENSE_IN * sizeof(float)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->bd, sizeof(float)));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->wd, dk, (size_t)OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->bd, db, sizeof(float), hipMemcpyDeviceToDevice, stream));
+  OVN_HIP_CHECK(hipStreamSynchronize(stream));
+  ctx->head_set = true;
+  return OVN_OK;
+}
+
+int ovn_finalize(ovn_ctx* ctx, int* feat_w) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_finalize: ctx is NULL");
+  OVN_REQUIRE(!ctx->leg.empty(), OVN_ERR_STATE, "ovn_finalize: no leg layers registered");
+  int h = ctx->in_h, w = ctx->in_w, c = ctx->in_c;
+  for (const auto& l : ctx->leg) {
+    OVN_REQUIRE(h >= l.kh && w >= l.kw, OVN_ERR_ARG, "ovn_finalize: layer %s does not fit its %dx%d input", l.name.c_str(), h, w);
+    h = (h - l.kh) / l.sh + 1;
+    w = (w - l.kw) / l.sw + 1;
+    c = l.cout;
+  }
+  OVN_REQUIRE(h == 1 && w == OVN_FEAT_W && c == OVN_FEAT_C, OVN_ERR_ARG,
+              "ovn_finalize: leg produces %dx%dx%d, the heads need 1x%dx%d", h, w, c, OVN_FEAT_W, OVN_FEAT_C);
+  ctx->feat_w = w;
+  ctx->finalized = true;
+  if (feat_w) *feat_w = w;
+  return OVN_OK;
+}
+
+int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_dev, void* stream_) {
+  OVN_REQUIRE(ctx && ctx->finalized, OVN_ERR_STATE, "ovn_leg: context not finalized");
+  OVN_REQUIRE(n >= 0, OVN_ERR_ARG, "ovn_leg: n < 0");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(images_dev && features_dev, OVN_ERR_ARG, "ovn_leg: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+  // largest intermediate activation per scan decides the ping-pong buffer size
+  size_t max_act = 0;
+  {
+    int h = ctx->in_h, w = ctx->in_w;
+    for (const auto& l : ctx->leg) {
+      h = (h - l.kh) / l.sh + 1;
+      w = (w - l.kw) / l.sw + 1;
+      const size_t e = (size_t)h * w * l.cout;
+      if (e > max_act) max_act = e;
+    }
+  }
+  // process the batch in slices so the scratch stays bounded (2 x slice x 850 KB at C=4)
+  const int64_t slice = 256;
+  const size_t buf_bytes = ((size_t)slice * max_act * sizeof(float) + 255) & ~(size_t)255;
+  int rc = ovn_ws_reserve(ctx, 2 * buf_bytes, stream);
+  if (rc) return rc;
+  float* buf[2] = {reinterpret_cast<float*>(ctx->ws), reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + buf_bytes)};
+  const size_t in_elems = (size_t)ctx->in_h * ctx->in_w * ctx->in_c;
+  for (int64_t s0 = 0; s0 < n; s0 += slice) {
+    const int nb = (int)((n - s0 < slice) ? (n - s0) : slice);
+    const float* cur = images_dev + (size_t)s0 * in_elems;
+    int h = ctx->in_h, w = ctx->in_w;
+    for (size_t li = 0; li < ctx->leg.size(); ++li) {
+      const bool last = (li + 1 == ctx->leg.size());
+      float* dst = last ? features_dev + (size_t)s0 * OVN_FEAT_ELEMS : buf[li & 1];
+      int oh = 0, ow = 0;
+      {
+        OvnProfScope ps(ctx, OVN_K_LEG, stream);
+        rc = ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream);
+      }
+      if (rc) return rc;
+      cur = dst;
+      h = oh;
+      w = ow;
+    }
+  }
+  return OVN_OK;
+}
+
+int ovn_corr_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+                  int64_t n, int32_t* yaw, float* corr, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_corr_head: ctx is NULL");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_corr_head: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(feats_l && feats_r && yaw, OVN_ERR_ARG, "ovn_corr_head: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OvnProfScope ps(ctx, OVN_K_CORR, (hipStream_t)stream);
+  return ovn_corr_forward(feats_l, lidx, feats_r, ridx, (int)n, yaw, corr, (hipStream_t)stream);
+}
+
+int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+              int64_t n, float* overlap, int32_t* yaw, float* logit, float* corr, void* stream_) {
+  OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_heads: head weights not set");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_heads: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(feats_l && feats_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t)stream_;
+
+  const size_t o2_elems = (size_t)OVN_G * OVN_G * OVN_C2_OUT;   // 24*24*128 per pair
+  const size_t o3_elems = (size_t)OVN_DENSE_IN;                 // 22*22*256 per pair
+  const int64_t chunk = 2048;                                   // pairs per pass: 1.6 GB of scratch
+  const int64_t cmax = n < chunk ? n : chunk;
+  const size_t o2_bytes = ((size_t)cmax * o2_elems * sizeof(float) + 255) & ~(size_t)255;
+  const size_t o3_bytes = ((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255;
+  int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes, stream);
+  if (rc) return rc;
+  float* o2 = reinterpret_cast<float*>(ctx->ws);
+  float* o3 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + o2_bytes);
+
+  ctx->dbg_o2 = o2;
+  ctx->dbg_o3 = o3;
+  ctx->dbg_n = cmax;
+  for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+    const int np = (int)((n - p0 < chunk) ? (n - p0) : chunk);
+    const float* fl = lidx ? feats_l : feats_l + (size_t)p0 * OVN_FEAT_ELEMS;
+    const int32_t* li = lidx ? lidx + p0 : nullptr;
+    const int32_t* ri = ridx ? ridx + p0 : nullptr;
+    {
+      OvnProfScope ps(ctx, OVN_K_CORR, stream);
+      rc = ovn_corr_forward(fl, li, feats_r, ri, np, yaw + p0, corr ? corr + (size_t)p0 * OVN_FEAT_W : nullptr, stream);
+    }
+    if (rc) return rc;
+    {
+      OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+      rc = ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
+    }
+    if (rc) return rc;
+    int oh = 0, ow = 0;
+    {
+      OvnProfScope ps(ctx, OVN_K_C3, stream);
+      rc = ovn_conv_forward(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream);
+    }
+    if (rc) return rc;
+    {
+      OvnProfScope ps(ctx, OVN_K_DENSE, stream);
+      rc = ovn_dense_sigmoid_forward(ctx, o3, np, overlap + p0, logit ? logit + p0 : nullptr, stream);
+    }
+    if (rc) return rc;
+  }
+  return OVN_OK;
+}
+
+int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_dev, int n_scans,
+                int64_t max_points_per_scan, int proj_h, int proj_w, double fov_up_deg, double fov_down_deg,
+                double max_range, float* range_dev, float* vertex_dev, float* intensity_dev, int32_t* idx_dev,
+                float* normal_dev, float* stacked_dev, int use_depth, int use_normals, int use_intensity, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_project: ctx is NULL");
+  OVN_REQUIRE(n_scans == 0 || (points_dev || max_points_per_scan == 0), OVN_ERR_ARG, "ovn_project: points is NULL");
+  OVN_REQUIRE(n_scans == 0 || offsets_dev, OVN_ERR_ARG, "ovn_project: offsets is NULL");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OvnProfScope ps(ctx, OVN_K_PROJ, (hipStream_t)stream);
+  return ovn_project_forward(ctx, points_dev, offsets_dev, n_scans, max_points_per_scan, proj_h, proj_w, fov_up_deg,
+                             fov_down_deg, max_range, range_dev, vertex_dev, intensity_dev, idx_dev, normal_dev,
+                             stacked_dev, use_depth, use_normals, use_intensity, (hipStream_t)stream);
+}
+
+int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,
+                float* normal_dev, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_normals: ctx is NULL");
+  OVN_REQUIRE(n_scans >= 0 && proj_h > 0 && proj_w > 0, OVN_ERR_ARG, "ovn_normals: bad sizes");
+  if (n_scans == 0) return OVN_OK;
+  OVN_REQUIRE(range_dev && vertex_dev && normal_dev, OVN_ERR_ARG, "ovn_normals: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return ovn_normals_forward(range_dev, vertex_dev, n_scans, proj_h, proj_w, normal_dev, (hipStream_t)stream);
+}
+
+int ovn_profile_begin(ovn_ctx* ctx) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_profile_begin: ctx is NULL");
+  for (auto& r : ctx->prof_recs) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  ctx->prof_recs.clear();
+  ctx->prof = true;
+  return OVN_OK;
+}
+
+int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind) {
+  OVN_REQUIRE(ctx && ms_by_kind && launches_by_kind, OVN_ERR_ARG, "ovn_profile_end: NULL argument");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  ctx->prof = false;
+  for (int k = 0; k < OVN_K_COUNT; ++k) {
+    ms_by_kind[k] = 0.0;
+    launches_by_kind[k] = 0;
+  }
+  int rc = OVN_OK;
+  for (auto& r : ctx->prof_recs) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) {
+      ovn_set_error("ovn_profile_end: %s", hipGetErrorString(e));
+      rc = OVN_ERR_HIP;
+    } else {
+      ms_by_kind[r.kind] += ms;
+      launches_by_kind[r.kind] += 1;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  ctx->prof_recs.clear();
+  return rc;
+}
+
+int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, int w, float* out_dev, void* stream) {
+  OVN_REQUIRE(ctx && layer >= 0 && layer < (int)ctx->leg.size(), OVN_ERR_ARG, "ovn_debug_conv: no such leg layer");
+  OVN_REQUIRE(in_dev && out_dev && nb >= 0, OVN_ERR_ARG, "ovn_debug_conv: bad buffers");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  int oh = 0, ow = 0;
+  return ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
+}
+
+int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream) {
+  OVN_REQUIRE(ctx && ctx->dbg_o2 && n >= 0 && n <= ctx->dbg_n, OVN_ERR_STATE,
+              "ovn_debug_head_activations: call right after ovn_heads with n <= its (first-chunk) pair count");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  if (o2_dev)
+    OVN_HIP_CHECK(hipMemcpyAsync(o2_dev, ctx->dbg_o2, (size_t)n * OVN_G * OVN_G * OVN_C2_OUT * sizeof(float),
+                                 hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  if (o3_dev)
+    OVN_HIP_CHECK(hipMemcpyAsync(o3_dev, ctx->dbg_o3, (size_t)n * OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+  return OVN_OK;
+}
+
+int64_t ovn_workspace_bytes(ovn_ctx* ctx) { return ctx ? (int64_t)ctx->ws_bytes : 0; }
+
+int ovn_selftest(ovn_ctx* ctx) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_selftest: ctx is NULL");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return ovn_mfma_selftest(nullptr);
+}
+
+}  // extern "C"

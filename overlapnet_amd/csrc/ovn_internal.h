@@ -1,0 +1,137 @@
+// Internal declarations shared by the translation units of libovn_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/ovn_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- error plumbing -------------------------------------------------------------------------------
+void ovn_set_error(const char* fmt, ...);
+
+#define OVN_HIP_CHECK(expr)                                                                   \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      ovn_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return OVN_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+#define OVN_REQUIRE(cond, code, ...)   \
+  do {                                 \
+    if (!(cond)) {                     \
+      ovn_set_error(__VA_ARGS__);      \
+      return (code);                   \
+    }                                  \
+  } while (0)
+
+// ---- feature geometry fixed by the reference network ----------------------------------------------
+constexpr int OVN_FEAT_W = 360;   // leg_output_width, config/network.yml:77
+constexpr int OVN_FEAT_C = 128;   // s_conv10 filters, generateNet.py:214
+constexpr int OVN_FEAT_ELEMS = OVN_FEAT_W * OVN_FEAT_C;
+constexpr int OVN_S = 15;         // conv1NetworkHead_conv1size default, generateNet.py:88-89
+constexpr int OVN_G = OVN_FEAT_W / OVN_S;            // 24
+constexpr int OVN_C1_OUT = 64;    // c_conv1 filters
+constexpr int OVN_C2_OUT = 128;   // c_conv2 filters
+constexpr int OVN_C3_OUT = 256;   // c_conv3 filters
+constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
+constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
+
+// ---- a convolution layer in MFMA fragment order ----------------------------------------------------
+struct OvnConvLayer {
+  std::string name;
+  int kh = 0, kw = 0, cin = 0, cout = 0, sh = 1, sw = 1;
+  int relu = 1;
+  int K = 0;      // kh*kw*cin
+  int nkc = 0;    // ceil(K/16)
+  float* wp = nullptr;    // [nkc][cout/16][64][4] fragment-ordered copy (device)
+  float* bias = nullptr;  // [cout] (device)
+};
+
+struct ovn_ctx {
+  int device = 0;
+  int in_h = 0, in_w = 0, in_c = 0;
+  std::vector<OvnConvLayer> leg;
+  bool finalized = false;
+  int feat_w = 0;
+  // head
+  bool head_set = false;
+  float* w1p = nullptr;  // c_conv1 in the K-permuted fragment order of the fused kernel
+  float* b1 = nullptr;
+  OvnConvLayer c2;       // c_conv2 as a [960][128] GEMM operand in fragment order
+  OvnConvLayer c3;       // c_conv3 as a regular conv layer
+  float* wd = nullptr;   // dense kernel [123904]
+  float* bd = nullptr;   // dense bias [1]
+  // scratch
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // where the last ovn_heads call left its c_conv2 / c_conv3 activations (first chunk), for tests
+  // optional per-kernel timing with HIP events on the launch stream (ovn_profile_begin/end)
+  bool prof = false;
+  struct ProfRec {
+    hipEvent_t a, b;
+    int kind;
+  };
+  std::vector<ProfRec> prof_recs;
+  const float* dbg_o2 = nullptr;
+  const float* dbg_o3 = nullptr;
+  int64_t dbg_n = 0;
+};
+
+// kernel classes reported by ovn_profile_end
+enum { OVN_K_LEG = 0, OVN_K_CORR = 1, OVN_K_DELTA = 2, OVN_K_C3 = 3, OVN_K_DENSE = 4, OVN_K_PROJ = 5, OVN_K_COUNT = 8 };
+
+struct OvnProfScope {
+  ovn_ctx* ctx;
+  hipStream_t stream;
+  hipEvent_t a = nullptr, b = nullptr;
+  int kind;
+  OvnProfScope(ovn_ctx* c, int k, hipStream_t s) : ctx(c), stream(s), kind(k) {
+    if (ctx->prof && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, stream);
+  }
+  ~OvnProfScope() {
+    if (ctx->prof && a && b) {
+      (void)hipEventRecord(b, stream);
+      ctx->prof_recs.push_back({a, b, kind});
+    }
+  }
+};
+
+int ovn_ws_reserve(ovn_ctx* ctx, size_t bytes, hipStream_t stream);
+
+// ---- kernels' host launchers (each returns an OVN_* code) ------------------------------------------
+// conv_f32.hip
+int ovn_conv_prepare(OvnConvLayer* L, const float* kernel_dev, const float* bias_dev, hipStream_t stream);
+void ovn_conv_release(OvnConvLayer* L);
+int ovn_conv_forward(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh,
+                     int* ow, hipStream_t stream);
+
+// delta_head.hip
+int ovn_delta_prepare_w1(const float* c1_kernel_dev, float** w1p_out, hipStream_t stream);
+int ovn_delta_c12_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                          const int32_t* ridx, int n, float* o2, hipStream_t stream);
+int ovn_dense_sigmoid_forward(const ovn_ctx* ctx, const float* o3, int n, float* overlap, float* logit,
+                              hipStream_t stream);
+
+// corr_head.hip
+int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+                     int n, int32_t* yaw, float* corr, hipStream_t stream);
+
+// projection.hip
+int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offsets, int n_scans,
+                        int64_t max_points, int H, int W, double fov_up_deg, double fov_down_deg,
+                        double max_range, float* range, float* vertex, float* intensity, int32_t* idx,
+                        float* normal, float* stacked, int use_depth, int use_normals, int use_intensity,
+                        hipStream_t stream);
+
+int ovn_normals_forward(const float* range, const float* vertex, int n_scans, int H, int W, float* normal,
+                        hipStream_t stream);
+
+// selftest.hip
+int ovn_mfma_selftest(hipStream_t stream);

@@ -1,0 +1,276 @@
+// Spherical projection (range / vertex / intensity / index images) and normal map for gfx950.
+// Compile this file with -ffp-contract=off: the float32 arithmetic below is written to round exactly
+// like the reference's NumPy code does, one IEEE operation at a time.
+//
+// Reference: src/utils/utils.py:59-134 (range_projection) and :137-186 (gen_normal_map, wrap).
+//   range_projection sorts the points by decreasing depth and scatters them so that the nearest point
+//   wins each pixel (:107-132).  Here the same winner is found without sorting: every kept point does a
+//   64-bit atomicMin of the key (float bits of depth << 32 | point index) on its pixel -- depth > 0 so
+//   the float bits order like the floats, and equal depths fall back to the lower point index.
+//   atan2/asin are evaluated in float64 and rounded to float32 (NumPy's float32 versions are only
+//   accurate to ~1 ulp, so bit-equality of the angles is not attainable; the pixel a point lands in
+//   is what matters and that is checked against the reference's shipped fixtures).
+//   gen_normal_map's per-pixel Python loop (:149-173) becomes one thread per pixel; the vector norm
+//   reproduces np.linalg.norm on a float32 3-vector (float32 products summed in a double -- OpenBLAS
+//   sdot's scalar tail -- then rounded to float32 and square-rooted).
+#include "ovn_internal.h"
+
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+constexpr int PB = 256;  // points per block in the scatter kernel
+
+struct ProjGeom {
+  int H, W;
+  float fov_down_abs;  // float32(|fov_down| in radians)
+  float fov;           // float32(|fov_down| + |fov_up|)
+  float max_range;
+};
+
+__global__ void proj_clear_kernel(unsigned long long* __restrict__ keys, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    keys[i] = EMPTY_KEY;
+}
+
+// grid = (ceil(max_points/PB), n_scans)
+__global__ __launch_bounds__(PB) void proj_scatter_kernel(const float* __restrict__ points,
+                                                          const long long* __restrict__ offsets, ProjGeom gm,
+                                                          unsigned long long* __restrict__ keys,
+                                                          int* __restrict__ local_idx, int* __restrict__ block_cnt,
+                                                          int blocks_per_scan, long long max_points) {
+  __shared__ int wave_cnt[PB / 64];
+  const int scan = blockIdx.y;
+  const long long beg = offsets[scan];
+  const long long npts = offsets[scan + 1] - beg;
+  const long long p = (long long)blockIdx.x * PB + threadIdx.x;
+  bool keep = false;
+  float depth = 0.f;
+  int pix = 0;
+  if (p < npts) {
+    const f32x4 pt = *reinterpret_cast<const f32x4*>(points + (beg + p) * 4);
+    const float x = pt[0], y = pt[1], z = pt[2];
+    depth = sqrtf((x * x + y * y) + z * z);                 // utils.py:75
+    keep = (depth > 0.0f) && (depth < gm.max_range);       // utils.py:76-77
+    if (keep) {
+      const float yaw = -(float)atan2((double)y, (double)x);     // utils.py:86
+      const float pitch = (float)asin((double)(z / depth));      // utils.py:87
+      float px = 0.5f * (yaw / 3.14159274101257324f + 1.0f);     // utils.py:90
+      float py = 1.0f - (pitch + gm.fov_down_abs) / gm.fov;      // utils.py:91
+      px = px * (float)gm.W;                                     // utils.py:94
+      py = py * (float)gm.H;                                     // utils.py:95
+      px = fmaxf(0.0f, fminf((float)(gm.W - 1), floorf(px)));    // utils.py:98-100
+      py = fmaxf(0.0f, fminf((float)(gm.H - 1), floorf(py)));    // utils.py:102-104
+      pix = (int)py * gm.W + (int)px;
+    }
+  }
+  if (keep) {
+    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (unsigned long long)(unsigned)p;
+    atomicMin(&keys[(long long)scan * gm.H * gm.W + pix], key);
+  }
+  if (local_idx) {
+    // index of this point among the KEPT points of its block (utils.py:117-118 numbers points after the filter)
+    const unsigned long long m = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    const int below = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_cnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += wave_cnt[w];
+    if (p < npts) local_idx[(long long)scan * max_points + p] = base + below;
+    if (threadIdx.x == 0) {
+      int tot = 0;
+      for (int w = 0; w < PB / 64; ++w) tot += wave_cnt[w];
+      block_cnt[(long long)scan * blocks_per_scan + blockIdx.x] = tot;
+    }
+  }
+}
+
+// exclusive scan of the per-block kept counts of every scan (a few hundred entries per scan)
+__global__ void proj_block_scan_kernel(int* __restrict__ block_cnt, int blocks_per_scan) {
+  if (threadIdx.x != 0) return;
+  int* c = block_cnt + (long long)blockIdx.x * blocks_per_scan;
+  int run = 0;
+  for (int b = 0; b < blocks_per_scan; ++b) {
+    const int v = c[b];
+    c[b] = run;
+    run += v;
+  }
+}
+
+// one thread per pixel: resolve the winner
+__global__ void proj_gather_kernel(const float* __restrict__ points, const long long* __restrict__ offsets,
+                                   const unsigned long long* __restrict__ keys, const int* __restrict__ local_idx,
+                                   const int* __restrict__ block_pref, int blocks_per_scan, long long max_points,
+                                   int HW, int n_scans,
+                                   float* __restrict__ range, float* __restrict__ vertex,
+                                   float* __restrict__ intensity, int32_t* __restrict__ idx) {
+  const long long total = (long long)n_scans * HW;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int scan = (int)(q / HW);
+    const unsigned long long key = keys[q];
+    f32x4 v = {-1.f, -1.f, -1.f, -1.f};
+    float d = -1.f, it = -1.f;
+    int id = -1;
+    if (key != EMPTY_KEY) {
+      const long long p = (long long)(key & 0xFFFFFFFFull);
+      const f32x4 pt = *reinterpret_cast<const f32x4*>(points + (offsets[scan] + p) * 4);
+      d = __uint_as_float((unsigned)(key >> 32));
+      it = pt[3];
+      v = (f32x4){pt[0], pt[1], pt[2], 1.0f};
+      if (idx) id = block_pref[(long long)scan * blocks_per_scan + (int)(p / PB)] + local_idx[(long long)scan * max_points + p];
+    }
+    range[q] = d;
+    *reinterpret_cast<f32x4*>(vertex + q * 4) = v;
+    if (intensity) intensity[q] = it;
+    if (idx) idx[q] = id;
+  }
+}
+
+__device__ __forceinline__ float norm3_like_numpy(float x, float y, float z) {
+  // np.linalg.norm(float32[3]) == sqrt(float32(double(x*x) + double(y*y) + double(z*z)))
+  const double s = ((double)(x * x) + (double)(y * y)) + (double)(z * z);
+  return sqrtf((float)s);
+}
+
+// one thread per pixel: normal (utils.py:149-173) + the stacked leg input
+__global__ void proj_normal_kernel(const float* __restrict__ range, const float* __restrict__ vertex,
+                                   const float* __restrict__ intensity, int H, int W, int n_scans,
+                                   float* __restrict__ normal, float* __restrict__ stacked, int use_depth,
+                                   int use_normals, int use_intensity, int C) {
+  const int HW = H * W;
+  const long long total = (long long)n_scans * HW;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
+       q += (long long)gridDim.x * blockDim.x) {
+    const int pix = (int)(q % HW);
+    const long long sbase = q - pix;
+    const int y = pix / W;
+    const int x = pix - y * W;
+    float nx = -1.f, ny = -1.f, nz = -1.f;
+    const float d = range[q];
+    if ((normal || (stacked && use_normals)) && y < H - 1 && d > 0.0f) {
+      const int xr = (x + 1 >= W) ? (x + 1 - W) : (x + 1);  // wrap(), utils.py:178-186
+      const long long qu = sbase + (long long)y * W + xr;
+      const long long qv = sbase + (long long)(y + 1) * W + x;
+      if (range[qu] > 0.0f && range[qv] > 0.0f) {
+        const f32x4 p = *reinterpret_cast<const f32x4*>(vertex + q * 4);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(vertex + qu * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(vertex + qv * 4);
+        const float ux = u[0] - p[0], uy = u[1] - p[1], uz = u[2] - p[2];
+        const float vx = v[0] - p[0], vy = v[1] - p[1], vz = v[2] - p[2];
+        const float un = norm3_like_numpy(ux, uy, uz);
+        const float vn = norm3_like_numpy(vx, vy, vz);
+        const float ax = vx / vn, ay = vy / vn, az = vz / vn;  // v_norm
+        const float bx = ux / un, by = uy / un, bz = uz / un;  // u_norm
+        const float wx = ay * bz - az * by;                    // np.cross(v_norm, u_norm), utils.py:168
+        const float wy = az * bx - ax * bz;
+        const float wz = ax * by - ay * bx;
+        const float wn = norm3_like_numpy(wx, wy, wz);
+        if (wn > 0.0f) {  // NaN fails the test and the pixel stays -1 (utils.py:170)
+          nx = wx / wn;
+          ny = wy / wn;
+          nz = wz / wn;
+        }
+      }
+    }
+    if (normal) {
+      normal[q * 3 + 0] = nx;
+      normal[q * 3 + 1] = ny;
+      normal[q * 3 + 2] = nz;
+    }
+    if (stacked) {
+      float* o = stacked + q * C;
+      int c = 0;
+      if (use_depth) o[c++] = d;
+      if (use_normals) {
+        o[c++] = nx;
+        o[c++] = ny;
+        o[c++] = nz;
+      }
+      if (use_intensity) o[c++] = intensity[q];
+    }
+  }
+}
+
+}  // namespace
+
+int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offsets, int n_scans, int64_t max_points,
+                        int H, int W, double fov_up_deg, double fov_down_deg, double max_range, float* range,
+                        float* vertex, float* intensity, int32_t* idx, float* normal, float* stacked, int use_depth,
+                        int use_normals, int use_intensity, hipStream_t stream) {
+  OVN_REQUIRE(n_scans >= 0 && H > 0 && W > 0 && max_points >= 0, OVN_ERR_ARG, "ovn_project: bad sizes");
+  OVN_REQUIRE(max_points < (1ll << 32), OVN_ERR_ARG, "ovn_project: more than 2^32 points per scan");
+  if (n_scans == 0) return OVN_OK;
+  const int C = (use_depth ? 1 : 0) + (use_normals ? 3 : 0) + (use_intensity ? 1 : 0);
+  OVN_REQUIRE(!stacked || C > 0, OVN_ERR_ARG, "ovn_project: stacked output requested with no channel enabled");
+
+  // same double arithmetic as utils.py:70-72, then the float32 casts NumPy applies to the scalars
+  const double up = fov_up_deg / 180.0 * 3.14159265358979323846;
+  const double down = fov_down_deg / 180.0 * 3.14159265358979323846;
+  ProjGeom gm;
+  gm.H = H;
+  gm.W = W;
+  gm.fov_down_abs = (float)fabs(down);
+  gm.fov = (float)(fabs(down) + fabs(up));
+  gm.max_range = (float)max_range;
+
+  const long long HW = (long long)H * W;
+  const long long npix = HW * n_scans;
+  const int blocks_per_scan = (int)((max_points + PB - 1) / PB) > 0 ? (int)((max_points + PB - 1) / PB) : 1;
+  const bool need_vertex = (vertex == nullptr);
+  const bool need_range = (range == nullptr);
+  const bool need_int = (intensity == nullptr) && (stacked && use_intensity);
+
+  // scratch carve-up (all 16-byte aligned)
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    size_t o = off;
+    off += (bytes + 255) & ~(size_t)255;
+    return o;
+  };
+  const size_t o_keys = carve((size_t)npix * 8);
+  const size_t o_lidx = idx ? carve((size_t)n_scans * (size_t)max_points * 4 + 16) : 0;
+  const size_t o_bcnt = idx ? carve((size_t)n_scans * blocks_per_scan * 4) : 0;
+  const size_t o_rng = need_range ? carve((size_t)npix * 4) : 0;
+  const size_t o_vtx = need_vertex ? carve((size_t)npix * 16) : 0;
+  const size_t o_int = need_int ? carve((size_t)npix * 4) : 0;
+  int rc = ovn_ws_reserve(ctx, off, stream);
+  if (rc) return rc;
+  char* ws = static_cast<char*>(ctx->ws);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + o_keys);
+  int* block_cnt = idx ? reinterpret_cast<int*>(ws + o_bcnt) : nullptr;
+  float* rng = need_range ? reinterpret_cast<float*>(ws + o_rng) : range;
+  float* vtx = need_vertex ? reinterpret_cast<float*>(ws + o_vtx) : vertex;
+  float* itn = need_int ? reinterpret_cast<float*>(ws + o_int) : intensity;
+
+  // local_idx is indexed [scan][point]: n_scans * max_points ints
+  int* local_idx = idx ? reinterpret_cast<int*>(ws + o_lidx) : nullptr;
+
+  hipLaunchKernelGGL(proj_clear_kernel, dim3(1024), dim3(256), 0, stream, keys, npix);
+  if (max_points > 0) {
+    hipLaunchKernelGGL(proj_scatter_kernel, dim3(blocks_per_scan, n_scans), dim3(PB), 0, stream, points,
+                       reinterpret_cast<const long long*>(offsets), gm, keys, local_idx, block_cnt, blocks_per_scan,
+                       (long long)max_points);
+    if (idx) hipLaunchKernelGGL(proj_block_scan_kernel, dim3(n_scans), dim3(64), 0, stream, block_cnt, blocks_per_scan);
+  }
+  const int gblocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+  hipLaunchKernelGGL(proj_gather_kernel, dim3(gblocks), dim3(256), 0, stream, points,
+                     reinterpret_cast<const long long*>(offsets), keys, local_idx, block_cnt, blocks_per_scan,
+                     (long long)max_points, (int)HW, n_scans, rng, vtx, itn, idx);
+  if (normal || stacked)
+    hipLaunchKernelGGL(proj_normal_kernel, dim3(gblocks), dim3(256), 0, stream, rng, vtx, itn, H, W, n_scans, normal,
+                       stacked, use_depth, use_normals, use_intensity, C);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+int ovn_normals_forward(const float* range, const float* vertex, int n_scans, int H, int W, float* normal,
+                        hipStream_t stream) {
+  const long long npix = (long long)H * W * n_scans;
+  if (npix == 0) return OVN_OK;
+  const int gblocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
+  hipLaunchKernelGGL(proj_normal_kernel, dim3(gblocks), dim3(256), 0, stream, range, vertex, (const float*)nullptr, H, W,
+                     n_scans, normal, (float*)nullptr, 0, 0, 0, 0);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}

@@ -1,0 +1,81 @@
+"""One-vs-N candidate sweep sharded over the GPUs of one node (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+Every candidate is an independent unit against the one query (no cross-candidate term anywhere in the
+reference's heads, generateNet.py:64-116,327-354), so the shards never exchange data on the compute
+path.  The only collective is the final gather of 8 bytes per candidate -- (overlap f32, yaw i32) -- to
+the root, issued once per query.  The reference has no distributed code; this is the multi-GPU form of
+`Infer.infer_multiple` (infer.py:162-203).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Contiguous block partition: the first (n mod world) ranks get one extra candidate."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    base, extra = divmod(int(n), world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def shard_sizes(n: int, world: int) -> List[int]:
+    return [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
+
+
+def pack_scores(overlap: torch.Tensor, yaw: torch.Tensor) -> torch.Tensor:
+    """(n) f32 + (n) i32 -> (n, 2) i32 payload (bit-cast, exact) so ONE collective moves both."""
+    return torch.stack([overlap.contiguous().view(torch.int32), yaw.to(torch.int32)], dim=1).contiguous()
+
+
+def unpack_scores(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    return buf[:, 0].contiguous().view(torch.float32), buf[:, 1].contiguous()
+
+
+def gather_scores(overlap: torch.Tensor, yaw: torch.Tensor, n_total: int, group=None, dst: int = 0
+                  ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+    """Gather the per-rank (overlap, yaw) shards, in candidate order, on rank `dst` (None elsewhere).
+    A single fixed-size collective: shards are padded to the largest shard size."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    sizes = shard_sizes(n_total, world)
+    if overlap.numel() != sizes[rank]:
+        raise ValueError("rank %d holds %d scores, its shard has %d" % (rank, overlap.numel(), sizes[rank]))
+    m = max(sizes) if sizes else 0
+    payload = torch.zeros((m, 2), dtype=torch.int32, device=overlap.device)
+    if overlap.numel():
+        payload[:overlap.numel()] = pack_scores(overlap, yaw)
+    if rank == dst:
+        bufs = [torch.empty_like(payload) for _ in range(world)]
+        dist.gather(payload, bufs, dst=dst, group=group)
+        cat = torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+        return unpack_scores(cat)
+    dist.gather(payload, None, dst=dst, group=group)
+    return None
+
+
+def sweep_one_vs_n(score_fn: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]], n_total: int, group=None,
+                   dst: int = 0):
+    """Run `score_fn(lo, hi)` -> (overlap, yaw) on this rank's block of the candidate pool and gather."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    lo, hi = shard_bounds(n_total, world, rank)
+    ov, yw = score_fn(lo, hi)
+    return gather_scores(ov, yw, n_total, group, dst)
+
+
+def best_match(overlap: torch.Tensor, yaw: torch.Tensor, threshold: float = 0.3):
+    """Loop-closure decision of demo3 (demo3_lcd.py:118-120): argmax overlap if it exceeds the threshold."""
+    if overlap.numel() == 0:
+        return None
+    i = int(torch.argmax(overlap))
+    if float(overlap[i]) > threshold:
+        return i, float(overlap[i]), int(yaw[i])
+    return None

@@ -1,0 +1,250 @@
+"""Thin host wrapper around one libovn_hip context (one per GPU per process).
+
+PyTorch-ROCm is used only as the owner of device memory and for the current HIP stream; every
+computation is a C-ABI call into the hand-written HIP kernels.  Nothing here falls back to torch
+math or to the CPU oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import weights as W
+
+FEAT_W = 360
+FEAT_C = 128
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise _lib.OvnError("no HIP device visible: overlapnet_amd runs on MI355X (gfx950) only, there is no CPU path")
+
+
+class OvnEngine:
+    """Owns the native context + device copies of nothing but the library's own re-tiled weights."""
+
+    def __init__(self, in_h: int = 64, in_w: int = 900, in_c: int = 4, device: Optional[int] = None):
+        _require_gpu()
+        self.lib = _lib.load()
+        self.device_index = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.in_h, self.in_w, self.in_c = int(in_h), int(in_w), int(in_c)
+        h = C.c_void_p()
+        _lib.check(self.lib.ovn_create(self.device_index, self.in_h, self.in_w, self.in_c, C.byref(h)), "ovn_create")
+        self._h = h
+        self.feat_w = 0
+        self._leg_ready = False
+        self._head_ready = False
+
+    # -- lifetime -----------------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.ovn_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- weights ------------------------------------------------------------------------------------
+    def load_weights(self, weights: Dict[str, np.ndarray], model_cfg: Optional[dict] = None) -> None:
+        """Register leg + head weights given by Keras layer name (reference infer.py:117-120)."""
+        cfg = model_cfg or {}
+        W.check_weights(weights, self.in_c, cfg)
+        if int(cfg.get("conv1NetworkHead_conv1size", 15)) != 15:
+            raise _lib.OvnError("the HIP Delta head is built for conv1NetworkHead_conv1size=15 (the reference default)")
+        with torch.cuda.device(self.device):
+            st = self._stream()
+            for l in W.leg_layers(self.in_c, cfg):
+                k = torch.from_numpy(np.ascontiguousarray(weights[l.name + "/kernel"], np.float32)).to(self.device)
+                b = torch.from_numpy(np.ascontiguousarray(weights[l.name + "/bias"], np.float32)).to(self.device)
+                _lib.check(self.lib.ovn_add_leg_layer(self._h, l.name.encode(), _ptr(k), _ptr(b), l.kh, l.kw, l.cin,
+                                                      l.cout, l.sh, l.sw, st), "ovn_add_leg_layer(%s)" % l.name)
+            fw = C.c_int(0)
+            _lib.check(self.lib.ovn_finalize(self._h, C.byref(fw)), "ovn_finalize")
+            self.feat_w = fw.value
+            self._leg_ready = True
+            names = ["c_conv1", "c_conv2", "c_conv3", "overlap_output"]
+            ts = []
+            for n in names:
+                ts.append(torch.from_numpy(np.ascontiguousarray(weights[n + "/kernel"], np.float32)).to(self.device))
+                ts.append(torch.from_numpy(np.ascontiguousarray(weights[n + "/bias"], np.float32)).to(self.device))
+            _lib.check(self.lib.ovn_set_head_weights(self._h, *[_ptr(t) for t in ts], st), "ovn_set_head_weights")
+            self._head_ready = True
+            torch.cuda.synchronize(self.device)
+
+    # -- leg ----------------------------------------------------------------------------------------
+    def leg(self, images: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """images (n, H, W, C) float32 on this device -> feature volumes (n, 360, 128)."""
+        if not self._leg_ready:
+            raise _lib.OvnError("leg weights not loaded")
+        if images.device != self.device or images.dtype != torch.float32 or not images.is_contiguous():
+            raise _lib.OvnError("leg input must be a contiguous float32 tensor on %s" % self.device)
+        if tuple(images.shape[1:]) != (self.in_h, self.in_w, self.in_c):
+            raise _lib.OvnError("leg input shape %s, expected (n,%d,%d,%d)" % (tuple(images.shape), self.in_h, self.in_w, self.in_c))
+        n = images.shape[0]
+        if out is None:
+            out = torch.empty((n, self.feat_w, FEAT_C), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_leg(self._h, _ptr(images), n, _ptr(out), self._stream()), "ovn_leg")
+        return out
+
+    # -- heads --------------------------------------------------------------------------------------
+    def _check_feats(self, t: torch.Tensor, what: str) -> None:
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.OvnError("%s must be a contiguous float32 tensor on %s" % (what, self.device))
+        if t.numel() % (FEAT_W * FEAT_C) != 0:
+            raise _lib.OvnError("%s is not a stack of 360x128 feature volumes" % what)
+
+    def _idx(self, idx, n: Optional[int]) -> Optional[torch.Tensor]:
+        if idx is None:
+            return None
+        t = torch.as_tensor(idx, dtype=torch.int32).to(self.device).contiguous()
+        if n is not None and t.numel() != n:
+            raise _lib.OvnError("index list has %d entries, expected %d" % (t.numel(), n))
+        return t
+
+    def heads(self, feats_l: torch.Tensor, feats_r: torch.Tensor, lidx=None, ridx=None, n: Optional[int] = None,
+              want_logit: bool = False, want_corr: bool = False):
+        """Both heads on n pairs: pair p = (l = feats_l[lidx[p]], r = feats_r[ridx[p]]).
+        lidx None -> p, ridx None -> 0 (1-vs-N: feats_r holds the single query).
+        Returns dict of device tensors: overlap (n) f32, yaw (n) i32 [, logit (n), corr (n,360)]."""
+        if not self._head_ready:
+            raise _lib.OvnError("head weights not loaded")
+        self._check_feats(feats_l, "feats_l")
+        self._check_feats(feats_r, "feats_r")
+        li = self._idx(lidx, None)
+        if n is None:
+            n = li.numel() if li is not None else feats_l.numel() // (FEAT_W * FEAT_C)
+        ri = self._idx(ridx, n)
+        if li is not None and li.numel() != n:
+            raise _lib.OvnError("lidx has %d entries, expected %d" % (li.numel(), n))
+        nl = feats_l.numel() // (FEAT_W * FEAT_C)
+        nr = feats_r.numel() // (FEAT_W * FEAT_C)
+        if li is None and n > nl:
+            raise _lib.OvnError("n=%d pairs but only %d left feature volumes" % (n, nl))
+        if n > 0:
+            if li is not None and (int(li.min()) < 0 or int(li.max()) >= nl):
+                raise IndexError("left pair index out of range")
+            if ri is not None and (int(ri.min()) < 0 or int(ri.max()) >= nr):
+                raise IndexError("right pair index out of range")
+        overlap = torch.empty(n, dtype=torch.float32, device=self.device)
+        yaw = torch.empty(n, dtype=torch.int32, device=self.device)
+        logit = torch.empty(n, dtype=torch.float32, device=self.device) if want_logit else None
+        corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_heads(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n, _ptr(overlap),
+                                          _ptr(yaw), _ptr(logit), _ptr(corr), self._stream()), "ovn_heads")
+        out = {"overlap": overlap, "yaw": yaw}
+        if want_logit:
+            out["logit"] = logit
+        if want_corr:
+            out["corr"] = corr
+        return out
+
+    def corr_head(self, feats_l: torch.Tensor, feats_r: torch.Tensor, lidx=None, ridx=None, n: Optional[int] = None,
+                  want_corr: bool = False):
+        self._check_feats(feats_l, "feats_l")
+        self._check_feats(feats_r, "feats_r")
+        li = self._idx(lidx, None)
+        if n is None:
+            n = li.numel() if li is not None else feats_l.numel() // (FEAT_W * FEAT_C)
+        ri = self._idx(ridx, n)
+        yaw = torch.empty(n, dtype=torch.int32, device=self.device)
+        corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_corr_head(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n, _ptr(yaw),
+                                              _ptr(corr), self._stream()), "ovn_corr_head")
+        return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
+
+    # -- preprocessing ------------------------------------------------------------------------------
+    def project(self, points: torch.Tensor, offsets: torch.Tensor, max_points: int, proj_h: int = 64,
+                proj_w: int = 900, fov_up: float = 3.0, fov_down: float = -25.0, max_range: float = 50.0,
+                want: Sequence[str] = ("range", "normal", "intensity"), stacked_flags: Optional[Tuple[bool, bool, bool]] = None):
+        """Batch spherical projection.  points: (total,4) f32 device tensor of concatenated scans,
+        offsets: (n_scans+1) int64 device tensor.  `want` selects outputs among
+        range, vertex, intensity, idx, normal; stacked_flags=(use_depth,use_normals,use_intensity)
+        additionally assembles the (n,H,W,C) leg input.  Returns a dict of device tensors."""
+        if points.device != self.device or points.dtype != torch.float32 or not points.is_contiguous():
+            raise _lib.OvnError("points must be a contiguous float32 tensor on %s" % self.device)
+        if offsets.device != self.device or offsets.dtype != torch.int64:
+            raise _lib.OvnError("offsets must be an int64 tensor on %s" % self.device)
+        n = offsets.numel() - 1
+        dev = self.device
+        out = {}
+        mk = lambda *shape, dt=torch.float32: torch.empty(shape, dtype=dt, device=dev)
+        rng = mk(n, proj_h, proj_w) if "range" in want else None
+        vtx = mk(n, proj_h, proj_w, 4) if "vertex" in want else None
+        itn = mk(n, proj_h, proj_w) if "intensity" in want else None
+        idx = mk(n, proj_h, proj_w, dt=torch.int32) if "idx" in want else None
+        nrm = mk(n, proj_h, proj_w, 3) if "normal" in want else None
+        stk = None
+        ud = un = ui = 0
+        if stacked_flags is not None:
+            ud, un, ui = (int(bool(v)) for v in stacked_flags)
+            stk = mk(n, proj_h, proj_w, ud + 3 * un + ui)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_project(self._h, _ptr(points), _ptr(offsets), n, int(max_points), proj_h, proj_w,
+                                            float(fov_up), float(fov_down), float(max_range), _ptr(rng), _ptr(vtx),
+                                            _ptr(itn), _ptr(idx), _ptr(nrm), _ptr(stk), ud, un, ui, self._stream()),
+                       "ovn_project")
+        for k, v in (("range", rng), ("vertex", vtx), ("intensity", itn), ("idx", idx), ("normal", nrm), ("stacked", stk)):
+            if v is not None:
+                out[k] = v
+        return out
+
+    def normals(self, rng: torch.Tensor, vtx: torch.Tensor) -> torch.Tensor:
+        """range (n,H,W) + vertex (n,H,W,4) device tensors -> normal map (n,H,W,3)."""
+        for t in (rng, vtx):
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.OvnError("normals(): inputs must be contiguous float32 tensors on %s" % self.device)
+        n, h, w = rng.shape
+        if tuple(vtx.shape) != (n, h, w, 4):
+            raise _lib.OvnError("normals(): vertex shape %s does not match range %s" % (tuple(vtx.shape), tuple(rng.shape)))
+        out = torch.empty((n, h, w, 3), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_normals(self._h, _ptr(rng), _ptr(vtx), n, h, w, _ptr(out), self._stream()),
+                       "ovn_normals")
+        return out
+
+    def debug_head_activations(self, n: int):
+        """(o2 (n,24,24,128), o3 (n,22,22,256)) left in scratch by the last heads() call -- test hook."""
+        o2 = torch.empty((n, 24, 24, 128), dtype=torch.float32, device=self.device)
+        o3 = torch.empty((n, 22, 22, 256), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_debug_head_activations(self._h, n, _ptr(o2), _ptr(o3), self._stream()),
+                       "ovn_debug_head_activations")
+        return o2, o3
+
+    PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection")
+
+    def profile_begin(self) -> None:
+        _lib.check(self.lib.ovn_profile_begin(self._h), "ovn_profile_begin")
+
+    def profile_end(self):
+        """{kind: (total_ms, launches)} measured with HIP events on the launch stream."""
+        ms = (C.c_double * 8)()
+        cnt = (C.c_int64 * 8)()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_profile_end(self._h, ms, cnt), "ovn_profile_end")
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
+
+    def selftest(self) -> None:
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_selftest(self._h), "ovn_selftest")
+
+    def workspace_bytes(self) -> int:
+        return int(self.lib.ovn_workspace_bytes(self._h))

@@ -1,0 +1,25 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (gfx950); run with `-m gpu` on the GPU box")
+
+
+@pytest.fixture(scope="session")
+def fixture_npz():
+    from overlapnet_amd import synthetic as S
+    return S.load_fixture_images()
+
+
+@pytest.fixture(scope="session")
+def nn_golden():
+    import numpy as np
+    with np.load(os.path.join(ROOT, "tests", "golden", "nn_oracle.npz")) as z:
+        return {k: z[k] for k in z.files}

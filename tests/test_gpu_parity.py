@@ -1,0 +1,317 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle and the golden vectors.
+
+Tolerances (north star: |d overlap| <= 1e-4, exact yaw bin):
+  * activations / corr vectors: max |gpu - fp64 oracle| <= 2e-5 * max|oracle|   (fp32 accumulate)
+  * logit: |d| <= 1e-3 * (1 + |logit|);  overlap: |d| <= 1e-4;  yaw: identical bin unless the oracle's
+    own top-2 gap is below 1e-5 relative (reported, not failed)
+  * projection: bit-identical images except <= 8 pixels per scan (float32 trig ulps at bin edges)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import overlapnet_oracle as O
+from overlapnet_amd import synthetic as S
+from overlapnet_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+CFG = S.REFERENCE_MODEL_CFG
+
+
+def _rel(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def engines():
+    from overlapnet_amd.engine import OvnEngine
+    out = {}
+    for C in (1, 4, 5):
+        e = OvnEngine(64, 900, C)
+        e.load_weights(S.make_test_weights(C, seed=0), CFG)
+        out[C] = e
+    yield out
+    for e in out.values():
+        e.close()
+
+
+@pytest.fixture(scope="module")
+def fixture_images(fixture_npz):
+    def make(C):
+        flags = S.flags_of(C)
+        return np.stack([S.stack(fixture_npz["range_%d" % i], fixture_npz["normal_%d" % i],
+                                 fixture_npz["intensity_%d" % i], flags) for i in range(2)])
+    return make
+
+
+def test_native_library_is_loaded_and_mfma_layout(engines):
+    import ctypes
+    from overlapnet_amd import _lib
+    assert isinstance(_lib.load(), ctypes.CDLL)
+    maps = open("/proc/self/maps").read()
+    assert "libovn_hip.so" in maps, "the in-tree HIP extension is not mapped into this process"
+    engines[4].selftest()
+
+
+@pytest.mark.parametrize("C", [1, 4, 5])
+def test_each_leg_layer_against_oracle(C):
+    """Every conv layer of the leg in isolation (vec4 and scalar gathers, K tails, M tails, all strides)."""
+    import ctypes
+    from overlapnet_amd import _lib
+    from overlapnet_amd.engine import OvnEngine, _ptr
+    rng = np.random.default_rng(100 + C)
+    w = S.make_test_weights(C, seed=1)
+    h, wd = 64, 900
+    for l in W.leg_layers(C, CFG):
+        eng = OvnEngine(h, wd, l.cin)
+        lib = eng.lib
+        nb = 3 if l.name == "s_conv1" else 2
+        x = rng.normal(size=(nb, h, wd, l.cin)).astype(np.float32)
+        k = w[l.name + "/kernel"]
+        b = w[l.name + "/bias"]
+        kt = torch.from_numpy(k).cuda()
+        bt = torch.from_numpy(b).cuda()
+        st = eng._stream()
+        _lib.check(lib.ovn_add_leg_layer(eng._h, l.name.encode(), _ptr(kt), _ptr(bt), l.kh, l.kw, l.cin, l.cout, l.sh,
+                                         l.sw, st), "add")
+        oh, ow = (h - l.kh) // l.sh + 1, (wd - l.kw) // l.sw + 1
+        xt = torch.from_numpy(x).cuda()
+        out = torch.empty((nb, oh, ow, l.cout), dtype=torch.float32, device="cuda")
+        rc = lib.ovn_debug_conv(eng._h, 0, _ptr(xt), nb, h, wd, _ptr(out), st)
+        _lib.check(rc, "ovn_debug_conv")
+        torch.cuda.synchronize()
+        ref = O._conv_valid(torch.from_numpy(x.astype(np.float64)).permute(0, 3, 1, 2), k, b, (l.sh, l.sw), True,
+                            torch.float64).permute(0, 2, 3, 1).numpy()
+        err = _rel(out.cpu().numpy(), ref)
+        assert err < 2e-5, "%s (C=%d): rel err %.3g" % (l.name, C, err)
+        eng.close()
+        h, wd = oh, ow
+    assert (h, wd) == (1, 360)
+
+
+@pytest.mark.parametrize("C", [1, 4, 5])
+def test_leg_against_oracle_and_golden(engines, fixture_images, nn_golden, C):
+    imgs = fixture_images(C)
+    fv = engines[C].leg(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    ref = O.leg_forward(imgs, S.make_test_weights(C, seed=0), CFG, np.float64).reshape(2, 360, 128)
+    assert fv.shape == (2, 360, 128)
+    assert _rel(fv, ref) < 2e-5
+    assert _rel(fv, nn_golden["fv_c%d" % C]) < 2e-5
+    # zero pattern of the ReLU output agrees except where the oracle value is within fp32 noise of 0
+    mism = (fv == 0) != (ref == 0)
+    assert np.all(np.abs(ref[mism]) < 1e-5 * np.max(ref))
+
+
+def test_leg_batch_tail_and_slicing(engines, fixture_images):
+    """n not a multiple of any tile, and > the internal 256-scan slice: same result per scan."""
+    imgs = fixture_images(4)
+    e = engines[4]
+    one = e.leg(torch.from_numpy(imgs[:1]).cuda())
+    many = torch.from_numpy(np.repeat(imgs[:1], 259, axis=0)).cuda()
+    out = e.leg(many)
+    assert torch.equal(out, one.expand(259, -1, -1))
+    assert e.leg(torch.empty((0, 64, 900, 4), device="cuda")).shape == (0, 360, 128)
+
+
+def _check_heads(eng, fv, pairs, w, want_intermediates=False):
+    fl = torch.from_numpy(np.ascontiguousarray(fv)).cuda()
+    r = eng.heads(fl, fl, lidx=pairs[:, 0], ridx=pairs[:, 1], want_logit=True, want_corr=True)
+    torch.cuda.synchronize()
+    fv4 = fv.reshape(-1, 1, 360, 128).astype(np.float64)
+    ov, yaw, lg, corr = O.heads_forward(fv4[pairs[:, 0]], fv4[pairs[:, 1]], w)
+    g_ov, g_yaw = r["overlap"].cpu().numpy(), r["yaw"].cpu().numpy()
+    g_lg, g_corr = r["logit"].cpu().numpy(), r["corr"].cpu().numpy()
+    assert _rel(g_corr, corr) < 2e-5, "corr vector rel err %.3g" % _rel(g_corr, corr)
+    srt = np.sort(corr, axis=1)
+    gap = (srt[:, -1] - srt[:, -2]) / np.abs(srt[:, -1])
+    bad = (g_yaw != yaw)
+    assert not np.any(bad & (gap > 1e-5)), "yaw bins differ: gpu %s oracle %s gaps %s" % (g_yaw[bad], yaw[bad], gap[bad])
+    # the yaw the kernel reports is the first argmax of the corr vector it reports
+    assert np.array_equal(g_yaw, 180 - np.argmax(g_corr, axis=1))
+    assert np.all(np.abs(g_lg - lg) <= 1e-3 * (1 + np.abs(lg))), "logit: gpu %s oracle %s" % (g_lg, lg)
+    assert np.max(np.abs(g_ov - ov)) <= 1e-4, "overlap: max err %.3g" % np.max(np.abs(g_ov - ov))
+    return g_ov, g_yaw, g_lg
+
+
+@pytest.mark.parametrize("C", [1, 4, 5])
+def test_heads_on_real_features(engines, fixture_images, C):
+    imgs = np.concatenate([fixture_images(C), S.candidate_images(6, C, seed=7)[2:]])
+    w = S.make_test_weights(C, seed=0)
+    fv = O.leg_forward(imgs, w, CFG, np.float32).reshape(-1, 360, 128)  # same fp32 inputs to both sides
+    pairs = np.array([[0, 1], [1, 0], [0, 0], [2, 0], [3, 1], [4, 5], [5, 2], [1, 1]])
+    _check_heads(engines[C], fv, pairs, w)
+
+
+def test_head_intermediates_against_oracle(engines):
+    """c_conv2 / c_conv3 activations of the fused Delta kernel (asymmetric random features so a swapped
+    l/r role or a transposed tile cannot pass)."""
+    rng = np.random.default_rng(11)
+    fv = np.maximum(rng.normal(0.3, 1.0, size=(3, 360, 128)), 0).astype(np.float32)
+    w = S.make_test_weights(4, seed=0)
+    e = engines[4]
+    fl = torch.from_numpy(fv).cuda()
+    pairs = np.array([[0, 1], [2, 0]])
+    e.heads(fl, fl, lidx=pairs[:, 0], ridx=pairs[:, 1])
+    o2, o3 = e.debug_head_activations(2)
+    for p in range(2):
+        l = fv[pairs[p, 0]].reshape(1, 1, 360, 128).astype(np.float64)
+        r = fv[pairs[p, 1]].reshape(1, 1, 360, 128).astype(np.float64)
+        _, _, inter = O.delta_head_forward(l, r, w, return_intermediates=True)
+        assert _rel(o2[p].cpu().numpy(), inter["o2"]) < 2e-5, "c_conv2 output, pair %d" % p
+        assert _rel(o3[p].cpu().numpy(), inter["o3"]) < 2e-5, "c_conv3 output, pair %d" % p
+
+
+def test_heads_random_features_many_pairs(engines):
+    rng = np.random.default_rng(21)
+    fv = np.maximum(rng.normal(0.2, 1.0, size=(9, 360, 128)), 0).astype(np.float32)
+    fv[3] = np.roll(fv[0], 25, axis=0)      # rolled copy -> known yaw
+    fv[4] *= 0                               # all-zero feature volume (dead scan)
+    pairs = np.array([[i, j] for i in range(9) for j in (0, 4, 7)][:20])
+    ov, yaw, lg = _check_heads(engines[4], fv, pairs, S.make_test_weights(4, seed=0))
+    # self pair -> yaw 0; rolled-by-25 left vs original right -> argmax 205 -> yaw -25
+    k = [tuple(p) for p in pairs.tolist()]
+    assert yaw[k.index((0, 0))] == 0 and yaw[k.index((3, 0))] == -25
+    # zero candidate vs zero query: corr is flat -> first maximum -> bin 0 -> yaw 180
+    assert yaw[k.index((4, 4))] == 180
+
+
+def test_one_vs_n_equals_indexed_pairs_and_is_deterministic(engines):
+    """1-vs-N sweep (ridx NULL -> query 0, lidx NULL -> identity) == the general indexed form, bit for bit,
+    across two runs and across the 2048-pair chunk boundary."""
+    rng = np.random.default_rng(31)
+    base = np.maximum(rng.normal(0.2, 1.0, size=(5, 360, 128)), 0).astype(np.float32)
+    n = 2051
+    cands = torch.from_numpy(base).cuda()[torch.arange(n) % 5].contiguous()
+    query = torch.from_numpy(base[1:2]).cuda().contiguous()
+    e = engines[4]
+    a = e.heads(cands, query, want_logit=True)
+    b = e.heads(cands, query, want_logit=True)
+    assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["yaw"], b["yaw"])
+    allf = torch.cat([query, cands])
+    c = e.heads(allf, allf, lidx=np.arange(1, n + 1), ridx=np.zeros(n, np.int64), want_logit=True)
+    assert torch.equal(a["logit"], c["logit"]) and torch.equal(a["yaw"], c["yaw"]) and torch.equal(a["overlap"], c["overlap"])
+    # periodic inputs -> periodic outputs (every candidate of the same residue class agrees exactly)
+    lg = a["logit"].cpu().numpy()
+    for r in range(5):
+        assert np.all(lg[r::5] == lg[r])
+    assert e.heads(cands[:0], query)["overlap"].shape == (0,)
+
+
+@pytest.mark.parametrize("scan", [0, 1])
+def test_projection_against_reference_golden(engines, fixture_npz, scan):
+    from overlapnet_amd import preprocess as P
+    pts = fixture_npz["points_%d" % scan]
+    r = P.project_scans([pts], engine=engines[4], want=("range", "vertex", "intensity", "idx", "normal"),
+                        stacked_flags=(True, True, True))
+    rng = r["range"][0].cpu().numpy()
+    ref = fixture_npz["range_%d" % scan]
+    diff = rng != ref
+    assert diff.sum() <= 8, "%d range pixels differ from the reference" % diff.sum()
+    same = ~diff
+    assert np.array_equal(r["intensity"][0].cpu().numpy()[same], fixture_npz["intensity_%d" % scan][same])
+    assert np.array_equal(r["idx"][0].cpu().numpy()[same], fixture_npz["idx_%d" % scan][same])
+    nrm = r["normal"][0].cpu().numpy()
+    ndiff = np.any(nrm != fixture_npz["normal_%d" % scan], axis=-1)
+    # a differing range pixel can disturb its own normal and its left / upper neighbour's
+    assert ndiff.sum() <= 3 * diff.sum(), "%d normal pixels differ (range diffs: %d)" % (ndiff.sum(), diff.sum())
+    stk = r["stacked"][0].cpu().numpy()
+    assert np.array_equal(stk[..., 0], rng) and np.array_equal(stk[..., 1:4], nrm)
+    assert np.array_equal(stk[..., 4], r["intensity"][0].cpu().numpy())
+    vtx = r["vertex"][0].cpu().numpy()
+    assert np.all(vtx[rng > 0][:, 3] == 1) and np.all(vtx[rng <= 0] == -1)
+    # stand-alone normal entry point == fused one
+    n2 = engines[4].normals(r["range"], r["vertex"])[0].cpu().numpy()
+    assert np.array_equal(n2, nrm)
+
+
+def test_projection_batch_ragged_and_edge_cases(engines, fixture_npz):
+    from overlapnet_amd import preprocess as P
+    p0, p1 = fixture_npz["points_0"], fixture_npz["points_1"]
+    empty = np.zeros((0, 4), np.float32)
+    far = np.array([[100, 0, 0, 1], [0, 0, 0, 1]], np.float32)
+    tie = np.array([[5, 0, 0, 0.3], [5, 0, 0, 0.7], [60, 1, 1, 0.1], [2, 0, 0, 0.9]], np.float32)
+    r = P.project_scans([p0, empty, p1[:1000], far, tie, p1], engine=engines[4],
+                        want=("range", "intensity", "idx", "normal"))
+    rng = r["range"].cpu().numpy()
+    single0 = P.project_scans([p0], engine=engines[4], want=("range", "normal", "idx"))
+    assert np.array_equal(rng[0], single0["range"][0].cpu().numpy())
+    assert np.array_equal(r["normal"][0].cpu().numpy(), single0["normal"][0].cpu().numpy())
+    assert np.array_equal(r["idx"][0].cpu().numpy(), single0["idx"][0].cpu().numpy())
+    assert np.all(rng[1] == -1) and np.all(rng[3] == -1) and np.all(r["idx"][1].cpu().numpy() == -1)
+    o_rng, _, o_int, o_idx = O.range_projection(p1[:1000], trig64=True)
+    assert np.array_equal(rng[2], o_rng) and np.array_equal(r["idx"][2].cpu().numpy(), o_idx)
+    t_rng, _, t_int, t_idx = O.range_projection(tie, trig64=True)
+    assert np.array_equal(rng[4], t_rng) and np.array_equal(r["intensity"][4].cpu().numpy(), t_int)
+    assert np.array_equal(r["idx"][4].cpu().numpy(), t_idx)
+    assert (rng[4] > 0).sum() == 1 and rng[4].max() == 2.0
+    assert np.array_equal(rng[5], P.project_scans([p1], engine=engines[4], want=("range",))["range"][0].cpu().numpy())
+
+
+def test_infer_class_end_to_end(tmp_path, fixture_npz):
+    """The drop-in `Infer` on .npy inputs laid out like demo1 writes them, against the oracle wired the way
+    the reference wires pair roles (infer.py:140-152,188-190,224-225)."""
+    from overlapnet_amd.infer import Infer
+    seq = tmp_path / "data" / "07"
+    for sub in ("depth", "normal", "intensity"):
+        os.makedirs(seq / sub)
+    imgs4 = []
+    for i in range(4):
+        s = i % 2
+        shift = 40 * (i // 2)
+        d = np.roll(fixture_npz["range_%d" % s], shift, axis=1)
+        nm = np.roll(fixture_npz["normal_%d" % s], shift, axis=1)
+        np.save(seq / "depth" / ("%06d.npy" % i), d)
+        np.save(seq / "normal" / ("%06d.npy" % i), nm)
+        imgs4.append(S.stack(d, nm, None, (True, True, False)))
+    imgs4 = np.stack(imgs4)
+    cfg = {"model": dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900]), "infer_seqs": "07",
+           "data_root_folder": str(tmp_path / "data"), "use_depth": True, "use_normals": True,
+           "use_class_probabilities": False, "use_class_probabilities_pca": False, "use_intensity": False,
+           "batch_size": 16, "pretrained_weightsfilename": ""}
+    w = S.make_test_weights(4, seed=0)
+    inf = Infer(cfg, weights=w)
+    assert cfg["model"]["inputShape"] == [64, 900, 4]  # mutated in place like infer.py:78-79
+    assert inf.no_input_channels == 4 and inf.batch_size == 16 and inf.network_output_size == 360
+
+    ref_fv = O.leg_forward(imgs4, w, CFG, np.float64)
+
+    def oracle(pairs):
+        return O.heads_forward(ref_fv[pairs[:, 0]], ref_fv[pairs[:, 1]], w)
+
+    # infer_one(f1, f2): filenames = [name2, name1]; l = fv[0] = name2, r = fv[1] = name1
+    ov, yaw = inf.infer_one("x/000000.bin", "y/000001.bin")
+    o_ov, o_yaw, _, _ = oracle(np.array([[1, 0]]))
+    assert ov.shape == (1,) and yaw.shape == (1,) and ov.dtype == np.float32
+    assert list(inf.filenames) == ["000001", "000000"]
+    assert abs(ov[0] - o_ov[0]) < 1e-4 and yaw[0] == o_yaw[0]
+    with pytest.raises(Exception, match="only works with .bin"):
+        inf.infer_one("a.txt", "b.bin")
+
+    fv = inf.create_feature_volumes(["000000", "000003"])
+    assert fv.shape == (2, 1, 360, 128) and _rel(fv[1, 0], ref_fv[3, 0]) < 2e-5
+
+    # infer_multiple: frames fed in order; l = reference frame, r = current frame
+    assert inf.infer_multiple(0, []) is None
+    r1 = inf.infer_multiple(1, [0])
+    assert r1[0].shape == () and r1[1].shape == (1,)        # squeeze -> 0-d when N == 1 (infer.py:197)
+    inf.infer_multiple(2, [])
+    ov3, yaw3 = inf.infer_multiple(3, [0, 1, 2])
+    o_ov, o_yaw, _, _ = oracle(np.array([[0, 3], [1, 3], [2, 3]]))
+    assert ov3.shape == (3,) and np.max(np.abs(ov3 - o_ov)) < 1e-4 and np.array_equal(yaw3, o_yaw)
+    assert len(inf.feature_volumes) == 4 and inf.feature_volumes[0].shape == (1, 360, 128)
+
+    # infer_multiple_vs_multiple: l = second_idxs, r = first_idxs
+    names = ["000000", "000001.bin", "d/000003.bin"]
+    ovm, yawm = inf.infer_multiple_vs_multiple(names, [0, 1, 2], [2, 1, 1])
+    o_ov, o_yaw, _, _ = oracle(np.array([[3, 0], [1, 1], [1, 3]]))
+    assert np.max(np.abs(ovm - o_ov)) < 1e-4 and np.array_equal(yawm, o_yaw)
+    assert inf.feature_volumes.shape == (3, 1, 360, 128)
+    assert inf.infer_multiple_vs_multiple(names, [], []) is None
+    with pytest.raises(Exception, match="same size"):
+        inf.infer_multiple_vs_multiple(names, [0], [])
+    cfg_bad = dict(cfg, model=dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900], legsType="360OutputkLegs_smaller"))
+    with pytest.raises(AttributeError):
+        Infer(cfg_bad, weights=w)
