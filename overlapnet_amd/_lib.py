@@ -67,6 +67,10 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64/libhsa-runtime64 under torch/lib.  Two HIP runtimes in one
+    # process do not work (the second one finds no device), so torch's copy must be mapped BEFORE
+    # libovn_hip.so is: the dynamic loader then binds our DT_NEEDED libamdhip64.so.7 to the loaded one.
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise OvnError("%s not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
                        "g.build()'` (or `make -C overlapnet_amd/csrc`). There is no CPU fallback." % LIB_PATH)

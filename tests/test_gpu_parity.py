@@ -126,7 +126,8 @@ def _check_heads(eng, fv, pairs, w, want_intermediates=False):
     g_lg, g_corr = r["logit"].cpu().numpy(), r["corr"].cpu().numpy()
     assert _rel(g_corr, corr) < 2e-5, "corr vector rel err %.3g" % _rel(g_corr, corr)
     srt = np.sort(corr, axis=1)
-    gap = (srt[:, -1] - srt[:, -2]) / np.abs(srt[:, -1])
+    with np.errstate(all="ignore"):
+        gap = np.nan_to_num((srt[:, -1] - srt[:, -2]) / np.abs(srt[:, -1]))
     bad = (g_yaw != yaw)
     assert not np.any(bad & (gap > 1e-5)), "yaw bins differ: gpu %s oracle %s gaps %s" % (g_yaw[bad], yaw[bad], gap[bad])
     # the yaw the kernel reports is the first argmax of the corr vector it reports
