@@ -36,6 +36,23 @@ HEAD_FLOP_PER_PAIR = 2_550_646_784          # whole Delta head (BASELINE.md sect
 CORR_FLOP_PER_PAIR = 33_177_600
 CAND_BYTES_PER_PAIR = 184_320 + 8           # candidate feature volume read once + (overlap, yaw) written
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse figure)
+
+
+def rocprof_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary under profiles/
+    (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; see
+    tools/summarize_rocprof.py) -- null if no summary names the kernel.  Counters cannot be read live in-process."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json"))):
+        try:
+            t = json.load(open(f)).get("hbm_traffic_per_launch", {})
+        except Exception:
+            continue
+        if kernel in t:
+            best = t[kernel]["total_bytes"]
+    return best
 
 
 def cpu_baseline(channels: int, pool: int):
@@ -82,6 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pool", type=int, default=1024, help="candidate feature volumes resident per GPU")
     ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
+    ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="Delta-head contraction arithmetic: fp32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against the fp64 oracle (untimed)")
     args = ap.parse_args()
@@ -103,6 +122,7 @@ def main():
     eng = OvnEngine(64, 900, C, device=local_rank)
     w = S.make_test_weights(C, seed=0)
     eng.load_weights(w, S.REFERENCE_MODEL_CFG)
+    eng.set_head_precision(args.head_precision)
 
     # ---- untimed setup: candidate pool -> feature volumes resident in HBM (each rank its own pool) ----
     fx = S.load_fixture_images()
@@ -152,19 +172,25 @@ def main():
         d_ms, d_n = prof["delta_c12"]
         avg_ms = d_ms / max(d_n, 1)
         achieved = DELTA_C12_FLOP_PER_PAIR * P / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
+        if args.head_precision == "f32":
+            peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, "delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)", "f32"
+            rl_note = "fp32 matrix cores, one MFMA per product"
+        else:
+            peak, kname, dtype = PEAK_BF16_MFMA_TFLOPS, "delta_c12_bf16x3_kernel (DeltaLayer+c_conv1+c_conv2, bf16 MFMA)", "bf16x3"
+            rl_note = ("achieved counts ALGORITHMIC flops; the 3-term bf16 split issues 3 MFMA flops per algorithmic "
+                       "flop, so the matrix pipe executes 3x this rate (frac <= 1/3 by construction)")
         kernels = {k: {"ms_per_launch": (v[0] / v[1] if v[1] else None), "launches": v[1]} for k, v in prof.items() if v[1]}
         out = {
             "metric": "scan-pairs/s (64x900 range images)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
                                    "64x900x%d range images" % (P, P, C),
                        "pairs_per_step": P * world, "channels": C, "weights": "seeded synthetic (no trained weights ship)",
                        "collective": "gather of (overlap,yaw) to rank 0 per step" if world > 1 else "none"},
-            "roofline": {"bound": "mfma", "kernel": "delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)",
-                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * P, "avg_launch_ms": avg_ms},
+            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": rocprof_traffic(kname.split(" ")[0]),
+                         "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * P, "avg_launch_ms": avg_ms, "note": rl_note},
             "kernels": kernels,
             "head_hbm_gbps_algorithmic": (P * world * args.steps / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
         }

@@ -108,6 +108,12 @@ int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_de
 int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,
                 float* normal_dev, void* stream);
 
+/* Arithmetic of the Delta head's c_conv1/c_conv2 contractions (storage and accumulation are fp32 either way):
+ *   0 = fp32 matrix cores (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 FMA chain),
+ *   1 = 3-term bf16 split on the bf16 matrix cores (x = hi + lo, a*w ~ ah*wh + al*wh + ah*wl; ~2^-17 per product)
+ *       -- the default; both modes are held to |d overlap| <= 1e-4 against the fp64 oracle by the parity tests. */
+int ovn_set_head_precision(ovn_ctx* ctx, int mode);
+
 /* Per-kernel-class timing with HIP events recorded on the launch stream, for bench.py's roofline line.
  * Between begin and end every kernel group launched through this context is bracketed by an event
  * pair; ovn_profile_end waits for them and returns, per class, the summed milliseconds and the number

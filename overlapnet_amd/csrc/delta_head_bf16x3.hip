@@ -1,0 +1,319 @@
+// Delta head, DeltaLayer + c_conv1 + c_conv2 fused, on the bf16 matrix cores with a 3-term split
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate) for gfx950.
+//
+// Same math and same work decomposition as delta_head.hip (reference generateNet.py:15-61, :96-106); what
+// changes is the arithmetic of each product.  Every fp32 operand x is written as hi + lo with
+// hi = bf16(x), lo = bf16(x - hi), and a*w is evaluated as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo: three MFMAs at the
+// bf16 rate (16x the fp32 matrix rate) instead of one fp32 MFMA.  The dropped a_lo*w_lo term and the rounding of
+// lo are ~2^-17 relative per product; sums are fp32.  The overlap tolerance of the north star (1e-4 after the
+// sigmoid, i.e. ~4e-4 on the logit) is checked against the fp64 oracle in tests/test_gpu_parity.py for this mode.
+//
+// One workgroup (8 waves) = one pair, wave w owns rows 48w..48w+47 (3 MFMA row tiles) of the 360 x 64 c_conv1
+// output of each column group jb.  K = (c, dj) is walked channel-slice-major: an MFMA step covers 32 channels
+// (lane group g = lane>>4 takes channels 32g + 8s .. 32g + 8s + 7 for slice s = 0..3) of one R row dj, and the
+// 15 rows dj of a slice are consecutive steps -- so a lane needs only 8 floats of L per row tile at a time
+// (24 VGPRs instead of 96; the next slice is prefetched from L2 while the current one is consumed).
+// |L-R| is formed and split on the VALU while the matrix pipe works on the previous step.  W1 (hi and lo, pre-permuted to this order) streams through a double-buffered
+// 2 x 16 KB LDS window shared by the 8 waves; o1 goes to LDS as hi/lo bf16 in GEMM2's [24][960] A layout.
+#include "ovn_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int FW = OVN_FEAT_W;        // 360
+constexpr int FC = OVN_FEAT_C;        // 128
+constexpr int S = OVN_S;              // 15
+constexpr int G = OVN_G;              // 24
+constexpr int O1 = OVN_C1_OUT;        // 64
+constexpr int O2 = OVN_C2_OUT;        // 128
+constexpr int K2 = S * O1;            // 960
+constexpr int O1_STRIDE = K2 + 8;     // bf16 elements per o1 row in LDS: 1936 B = 121 16-B slots (odd)
+constexpr int NCHUNK = 2 * S;         // W1 half-dj chunks per column group
+constexpr int CHUNK_BYTES = 16384;    // [s(2)][nt(4)][hi/lo][lane(64)][8 bf16]
+constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + (size_t)S * FC * 4 + 2 * CHUNK_BYTES;
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// |d0|, |d1| -> packed bf16 pairs (element 0 in the low half).  hi = |d| truncated to bf16 (one AND also strips
+// the sign), lo = bf16_rne(|d| - hi): |d| - hi is exact in fp32, so hi + lo carries |d| to ~2^-17 relative.
+__device__ __forceinline__ void split_pair(float d0, float d1, unsigned& hi_pk, unsigned& lo_pk) {
+  const unsigned h0 = __float_as_uint(d0) & 0x7fff0000u;
+  const unsigned h1 = __float_as_uint(d1) & 0x7fff0000u;
+  const float l0 = fabsf(d0) - __uint_as_float(h0);
+  const float l1 = fabsf(d1) - __uint_as_float(h1);
+  hi_pk = (h0 >> 16) | h1;
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 lp;
+  lp[0] = (__bf16)l0;
+  lp[1] = (__bf16)l1;
+  lo_pk = __builtin_bit_cast(unsigned, lp);
+}
+
+__device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
+  hi = (__bf16)x;
+  lo = (__bf16)(x - (float)hi);
+}
+
+// W1p[u = s*15 + dj][nt(4)][hl(2)][lane(64)][e(8)]: W1[dj][c = 32*(lane>>4) + 8*s + e][o = 16*nt + (lane&15)]
+__global__ void delta_prep_w1_bf16_kernel(const float* __restrict__ w1, __bf16* __restrict__ w1p) {
+  const int total = S * 4 * 4 * 64 * 8;  // (hi, lo) pairs
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 3;
+    const int u = idx >> 11;  // 0..59
+    const int s = u / S;
+    const int dj = u - s * S;
+    const int c = 32 * (lane >> 4) + 8 * s + e;
+    const int o = 16 * nt + (lane & 15);
+    __bf16 hi, lo;
+    split_bf16(w1[(dj * FC + c) * O1 + o], hi, lo);
+    const size_t base = (((size_t)u * 4 + nt) * 2) * 512 + lane * 8 + e;
+    w1p[base] = hi;
+    w1p[base + 512] = lo;
+  }
+}
+
+// W2p[ks(30)][nt(8)][hl(2)][lane(64)][e(8)]: W2[k = 32*ks + 8*(lane>>4) + e][p = 16*nt + (lane&15)], k = di*64 + o
+__global__ void delta_prep_w2_bf16_kernel(const float* __restrict__ w2, __bf16* __restrict__ w2p) {
+  const int total = (K2 / 32) * 8 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 7;
+    const int ks = idx >> 12;
+    const int k = 32 * ks + 8 * (lane >> 4) + e;
+    const int p = 16 * nt + (lane & 15);
+    __bf16 hi, lo;
+    split_bf16(w2[k * O2 + p], hi, lo);
+    const size_t base = (((size_t)ks * 8 + nt) * 2) * 512 + lane * 8 + e;
+    w2p[base] = hi;
+    w2p[base + 512] = lo;
+  }
+}
+
+__global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __restrict__ feats_l,
+                                                               const int32_t* __restrict__ lidx,
+                                                               const float* __restrict__ feats_r,
+                                                               const int32_t* __restrict__ ridx,
+                                                               const __bf16* __restrict__ w1p,
+                                                               const float* __restrict__ b1,
+                                                               const __bf16* __restrict__ w2p,
+                                                               const float* __restrict__ b2, float* __restrict__ o2) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* o1h = reinterpret_cast<__bf16*>(smem_raw);
+  __bf16* o1l = o1h + G * O1_STRIDE;
+  float* rs = reinterpret_cast<float*>(o1l + G * O1_STRIDE);
+  unsigned char* wst = reinterpret_cast<unsigned char*>(rs + S * FC);  // 2 x 16 KB
+
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const float* L = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
+  const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+
+  // this lane's slice of L for channel slice s: rows 48*wave + 16*t + lrow, channels 32g + 8s .. +7
+  int lrow_off[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int i = 48 * wave + 16 * t + lrow;
+    lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
+  }
+  f32x4 lcur[3][2], lnext[3][2];
+#define OVN_LOAD_L(DST, SL)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                        \
+    if (lrow_off[t] >= 0) {                                                                              \
+      DST[t][0] = *reinterpret_cast<const f32x4*>(L + lrow_off[t] + 8 * (SL));                           \
+      DST[t][1] = *reinterpret_cast<const f32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                       \
+    } else {                                                                                             \
+      DST[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
+      DST[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
+    }                                                                                                    \
+  }
+  OVN_LOAD_L(lcur, 0)
+  OVN_LOAD_L(lnext, 1)
+
+  // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 30 chunks, so the window just wraps)
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  f32x4 pf[2];
+  pf[0] = *reinterpret_cast<const f32x4*>(w1bytes + tid * 16);
+  pf[1] = *reinterpret_cast<const f32x4*>(w1bytes + 8192 + tid * 16);
+  *reinterpret_cast<f32x4*>(wst + tid * 16) = pf[0];
+  *reinterpret_cast<f32x4*>(wst + 8192 + tid * 16) = pf[1];
+  int cur = 0;
+  int sl = 0;  // channel slice of the current step (runs 0,1,2,3,0,... across column groups)
+  int dj = 0;
+
+  for (int jb = 0; jb < G; ++jb) {
+    __syncthreads();  // previous group's GEMM2 is done with o1h/o1l and rs; W window write above is visible
+    if (tid < S * FC / 4)
+      *reinterpret_cast<f32x4*>(rs + 4 * tid) = *reinterpret_cast<const f32x4*>(R + jb * S * FC + 4 * tid);
+    __syncthreads();
+
+    f32x4 acc[3][4];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+      const int nxt = (ch + 1 == NCHUNK) ? 0 : ch + 1;
+      const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;
+      pf[0] = *reinterpret_cast<const f32x4*>(src + tid * 16);
+      pf[1] = *reinterpret_cast<const f32x4*>(src + 8192 + tid * 16);
+
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        // one MFMA step: K = 32 channels of R row dj, 3 row tiles x 4 column tiles x 3 split terms
+        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * 8192;
+        const float* rrow = rs + dj * FC + 32 * g + 8 * sl;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rrow);
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rrow + 4);
+        bf16x8 bh[4], bl[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);
+          bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const f32x4 l0 = lcur[t][0], l1 = lcur[t][1];
+          unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+          split_pair(l0[0] - r0[0], l0[1] - r0[1], h0, q0);
+          split_pair(l0[2] - r0[2], l0[3] - r0[3], h1, q1);
+          split_pair(l1[0] - r1[0], l1[1] - r1[1], h2, q2);
+          split_pair(l1[2] - r1[2], l1[3] - r1[3], h3, q3);
+          const u32x4 ahp = {h0, h1, h2, h3};
+          const u32x4 alp = {q0, q1, q2, q3};
+          const bf16x8 ah = __builtin_bit_cast(bf16x8, ahp);
+          const bf16x8 al = __builtin_bit_cast(bf16x8, alp);
+          // consecutive MFMAs hit different accumulators (dependent distance = 4 instructions)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[t][nt], 0, 0, 0);
+        }
+        if (++dj == S) {  // slice finished: rotate in the prefetched slice, start fetching the one after
+          dj = 0;
+          sl = (sl + 1) & 3;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            lcur[t][0] = lnext[t][0];
+            lcur[t][1] = lnext[t][1];
+          }
+          const int sn = (sl + 1) & 3;
+          OVN_LOAD_L(lnext, sn)
+        }
+      }
+
+      unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;
+      *reinterpret_cast<f32x4*>(dstw + tid * 16) = pf[0];
+      *reinterpret_cast<f32x4*>(dstw + 8192 + tid * 16) = pf[1];
+      __syncthreads();
+      cur ^= 1;
+    }
+
+    // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int o = 16 * nt + lrow;
+      const float bv = b1[o];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 48 * wave + 16 * t + 4 * g + r;
+          if (i < FW) {
+            const int ib = i / S;
+            const int di = i - ib * S;
+            __bf16 h, l;
+            split_bf16(acc[t][nt][r] + bv, h, l);
+            o1h[ib * O1_STRIDE + di * O1 + o] = h;
+            o1l[ib * O1_STRIDE + di * O1 + o] = l;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // GEMM2 (24 x 960) x (960 x 128): wave -> m-tile (wave&1), n-tiles 2*(wave>>1), +1
+    {
+      const int mt = wave & 1;
+      const int ntp = wave >> 1;
+      int ib = 16 * mt + lrow;
+      if (ib > G - 1) ib = G - 1;
+      const __bf16* ahp = o1h + ib * O1_STRIDE + 8 * g;
+      const __bf16* alp = o1l + ib * O1_STRIDE + 8 * g;
+      const __bf16* wcol = w2p + ((size_t)(2 * ntp) * 2) * 512 + lane * 8;
+      f32x4 acc2[2];
+      acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+      for (int ks = 0; ks < K2 / 32; ++ks) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ahp + 32 * ks);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(alp + 32 * ks);
+        const __bf16* wk = wcol + (size_t)ks * (8 * 2 * 512);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wk + (q * 2 + 0) * 512);
+          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wk + (q * 2 + 1) * 512);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc2[q], 0, 0, 0);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc2[q], 0, 0, 0);
+          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc2[q], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int p = 16 * (2 * ntp + q) + lrow;
+        const float bv = b2[p];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ib2 = 16 * mt + 4 * g + r;
+          if (ib2 < G) o2[(((long long)pair * G + ib2) * G + jb) * O2 + p] = fmaxf(acc2[q][r] + bv, 0.0f);
+        }
+      }
+    }
+  }
+}
+
+#undef OVN_LOAD_L
+}  // namespace
+
+int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_dev, void** w1p_out, void** w2p_out,
+                             hipStream_t stream) {
+  const size_t w1_elems = (size_t)S * FC * O1 * 2;   // hi + lo
+  const size_t w2_elems = (size_t)K2 * O2 * 2;
+  OVN_HIP_CHECK(hipMalloc(w1p_out, w1_elems * sizeof(__bf16)));
+  OVN_HIP_CHECK(hipMalloc(w2p_out, w2_elems * sizeof(__bf16)));
+  hipLaunchKernelGGL(delta_prep_w1_bf16_kernel, dim3(240), dim3(256), 0, stream, c1_kernel_dev,
+                     reinterpret_cast<__bf16*>(*w1p_out));
+  hipLaunchKernelGGL(delta_prep_w2_bf16_kernel, dim3(240), dim3(256), 0, stream, c2_kernel_dev,
+                     reinterpret_cast<__bf16*>(*w2p_out));
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                 const int32_t* ridx, int n, float* o2, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(delta_c12_bf16x3_kernel, dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
+                     reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
+                     ctx->c2.bias, o2);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}

@@ -66,6 +66,8 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->b1) (void)hipFree(ctx->b1);
   if (ctx->wd) (void)hipFree(ctx->wd);
   if (ctx->bd) (void)hipFree(ctx->bd);
+  if (ctx->w1p_bf) (void)hipFree(ctx->w1p_bf);
+  if (ctx->w2p_bf) (void)hipFree(ctx->w2p_bf);
   if (ctx->ws) (void)hipFree(ctx->ws);
   delete ctx;
   return OVN_OK;
@@ -107,6 +109,9 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
     if (ctx->b1) (void)hipFree(ctx->b1);
     if (ctx->wd) (void)hipFree(ctx->wd);
     if (ctx->bd) (void)hipFree(ctx->bd);
+    if (ctx->w1p_bf) (void)hipFree(ctx->w1p_bf);
+    if (ctx->w2p_bf) (void)hipFree(ctx->w2p_bf);
+    ctx->w1p_bf = ctx->w2p_bf = nullptr;
     ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
     ctx->head_set = false;
   }
@@ -125,6 +130,8 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
   ctx->c2.sw = 1;
   ctx->c2.relu = 1;
   rc = ovn_conv_prepare(&ctx->c2, c2k, c2b, stream);
+  if (rc) return rc;
+  rc = ovn_delta_prepare_bf16x3(c1k, c2k, &ctx->w1p_bf, &ctx->w2p_bf, stream);
   if (rc) return rc;
   ctx->c3 = OvnConvLayer();
   ctx->c3.name = "c_conv3";
@@ -256,7 +263,8 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
     if (rc) return rc;
     {
       OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-      rc = ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
+      rc = (ctx->head_mode == 0) ? ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream)
+                                 : ovn_delta_c12_bf16x3_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
     }
     if (rc) return rc;
     int oh = 0, ow = 0;
@@ -296,6 +304,13 @@ int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, i
   OVN_REQUIRE(range_dev && vertex_dev && normal_dev, OVN_ERR_ARG, "ovn_normals: NULL buffer");
   OVN_HIP_CHECK(hipSetDevice(ctx->device));
   return ovn_normals_forward(range_dev, vertex_dev, n_scans, proj_h, proj_w, normal_dev, (hipStream_t)stream);
+}
+
+int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
+  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  ctx->head_mode = mode;
+  return OVN_OK;
 }
 
 int ovn_profile_begin(ovn_ctx* ctx) {

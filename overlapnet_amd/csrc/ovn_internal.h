@@ -66,6 +66,9 @@ struct ovn_ctx {
   float* b1 = nullptr;
   OvnConvLayer c2;       // c_conv2 as a [960][128] GEMM operand in fragment order
   OvnConvLayer c3;       // c_conv3 as a regular conv layer
+  void* w1p_bf = nullptr;  // c_conv1 hi/lo bf16 fragments (delta_head_bf16x3.hip)
+  void* w2p_bf = nullptr;  // c_conv2 hi/lo bf16 fragments
+  int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = 3-term bf16 split on the bf16 MFMA
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
   // scratch
@@ -118,6 +121,12 @@ int ovn_delta_c12_forward(const ovn_ctx* ctx, const float* feats_l, const int32_
                           const int32_t* ridx, int n, float* o2, hipStream_t stream);
 int ovn_dense_sigmoid_forward(const ovn_ctx* ctx, const float* o3, int n, float* overlap, float* logit,
                               hipStream_t stream);
+
+// delta_head_bf16x3.hip
+int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_dev, void** w1p_out, void** w2p_out,
+                             hipStream_t stream);
+int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                 const int32_t* ridx, int n, float* o2, hipStream_t stream);
 
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,

@@ -43,6 +43,7 @@ class OvnEngine:
         self.feat_w = 0
         self._leg_ready = False
         self._head_ready = False
+        self.head_precision = "bf16x3"
 
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:
@@ -228,6 +229,14 @@ class OvnEngine:
             _lib.check(self.lib.ovn_debug_head_activations(self._h, n, _ptr(o2), _ptr(o3), self._stream()),
                        "ovn_debug_head_activations")
         return o2, o3
+
+    def set_head_precision(self, mode: str) -> None:
+        """'f32' = fp32 matrix cores, 'bf16x3' = 3-term bf16 split on the bf16 matrix cores (default)."""
+        table = {"f32": 0, "bf16x3": 1}
+        if mode not in table:
+            raise ValueError("head precision must be one of %s" % sorted(table))
+        _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
+        self.head_precision = mode
 
     PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection")
 

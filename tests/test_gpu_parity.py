@@ -116,12 +116,28 @@ def test_leg_batch_tail_and_slicing(engines, fixture_images):
     assert e.leg(torch.empty((0, 64, 900, 4), device="cuda")).shape == (0, 360, 128)
 
 
-def _check_heads(eng, fv, pairs, w, want_intermediates=False):
+PRECISIONS = ("f32", "bf16x3")   # arithmetic of the Delta head contractions (ovn_set_head_precision)
+ACT_TOL = {"f32": 2e-5, "bf16x3": 6e-5}
+
+
+def _check_heads(eng, fv, pairs, w, oracle_cache=None):
+    fv4 = fv.reshape(-1, 1, 360, 128).astype(np.float64)
+    ov, yaw, lg, corr = O.heads_forward(fv4[pairs[:, 0]], fv4[pairs[:, 1]], w)
+    out = None
+    for mode in PRECISIONS:
+        eng.set_head_precision(mode)
+        try:
+            out = _check_heads_mode(eng, fv, pairs, (ov, yaw, lg, corr), mode)
+        finally:
+            eng.set_head_precision("bf16x3")
+    return out
+
+
+def _check_heads_mode(eng, fv, pairs, oracle, mode):
+    ov, yaw, lg, corr = oracle
     fl = torch.from_numpy(np.ascontiguousarray(fv)).cuda()
     r = eng.heads(fl, fl, lidx=pairs[:, 0], ridx=pairs[:, 1], want_logit=True, want_corr=True)
     torch.cuda.synchronize()
-    fv4 = fv.reshape(-1, 1, 360, 128).astype(np.float64)
-    ov, yaw, lg, corr = O.heads_forward(fv4[pairs[:, 0]], fv4[pairs[:, 1]], w)
     g_ov, g_yaw = r["overlap"].cpu().numpy(), r["yaw"].cpu().numpy()
     g_lg, g_corr = r["logit"].cpu().numpy(), r["corr"].cpu().numpy()
     assert _rel(g_corr, corr) < 2e-5, "corr vector rel err %.3g" % _rel(g_corr, corr)
@@ -132,8 +148,9 @@ def _check_heads(eng, fv, pairs, w, want_intermediates=False):
     assert not np.any(bad & (gap > 1e-5)), "yaw bins differ: gpu %s oracle %s gaps %s" % (g_yaw[bad], yaw[bad], gap[bad])
     # the yaw the kernel reports is the first argmax of the corr vector it reports
     assert np.array_equal(g_yaw, 180 - np.argmax(g_corr, axis=1))
-    assert np.all(np.abs(g_lg - lg) <= 1e-3 * (1 + np.abs(lg))), "logit: gpu %s oracle %s" % (g_lg, lg)
-    assert np.max(np.abs(g_ov - ov)) <= 1e-4, "overlap: max err %.3g" % np.max(np.abs(g_ov - ov))
+    assert np.all(np.abs(g_lg - lg) <= 1e-3 * (1 + np.abs(lg))), "[%s] logit: gpu %s oracle %s" % (mode, g_lg, lg)
+    assert np.max(np.abs(g_ov - ov)) <= 1e-4, "[%s] overlap: max err %.3g" % (mode, np.max(np.abs(g_ov - ov)))
+    print("[%s] max |d overlap| %.3g  max |d logit| %.3g" % (mode, np.max(np.abs(g_ov - ov)), np.max(np.abs(g_lg - lg))))
     return g_ov, g_yaw, g_lg
 
 
@@ -155,14 +172,23 @@ def test_head_intermediates_against_oracle(engines):
     e = engines[4]
     fl = torch.from_numpy(fv).cuda()
     pairs = np.array([[0, 1], [2, 0]])
-    e.heads(fl, fl, lidx=pairs[:, 0], ridx=pairs[:, 1])
-    o2, o3 = e.debug_head_activations(2)
+    inters = []
     for p in range(2):
         l = fv[pairs[p, 0]].reshape(1, 1, 360, 128).astype(np.float64)
         r = fv[pairs[p, 1]].reshape(1, 1, 360, 128).astype(np.float64)
-        _, _, inter = O.delta_head_forward(l, r, w, return_intermediates=True)
-        assert _rel(o2[p].cpu().numpy(), inter["o2"]) < 2e-5, "c_conv2 output, pair %d" % p
-        assert _rel(o3[p].cpu().numpy(), inter["o3"]) < 2e-5, "c_conv3 output, pair %d" % p
+        inters.append(O.delta_head_forward(l, r, w, return_intermediates=True)[2])
+    for mode in PRECISIONS:
+        e.set_head_precision(mode)
+        try:
+            e.heads(fl, fl, lidx=pairs[:, 0], ridx=pairs[:, 1])
+            o2, o3 = e.debug_head_activations(2)
+        finally:
+            e.set_head_precision("bf16x3")
+        for p in range(2):
+            e2, e3 = _rel(o2[p].cpu().numpy(), inters[p]["o2"]), _rel(o3[p].cpu().numpy(), inters[p]["o3"])
+            print("[%s] pair %d: c_conv2 rel err %.3g, c_conv3 rel err %.3g" % (mode, p, e2, e3))
+            assert e2 < ACT_TOL[mode], "[%s] c_conv2 output, pair %d: %.3g" % (mode, p, e2)
+            assert e3 < ACT_TOL[mode], "[%s] c_conv3 output, pair %d: %.3g" % (mode, p, e3)
 
 
 def test_heads_random_features_many_pairs(engines):
