@@ -1,0 +1,289 @@
+// Valid-padded NHWC convolution + bias (+ReLU) as an implicit GEMM on the bf16 matrix cores with the 3-term
+// split (x = hi + lo in bf16, a*w ~ ah*wh + al*wh + ah*wl, fp32 accumulate) for gfx950.
+//
+// Same contract, GEMM view and gather scheme as conv_f32.hip (reference: Keras Conv2D(padding='valid'),
+// generateNet.py:108-110 for c_conv3, :161-214 for the leg); used where fp32 matrix-core time dominates.
+// The K loop advances 32 at a time (one v_mfma_f32_16x16x32_bf16 step).  A-tile values are split into hi/lo
+// bf16 ONCE when they are staged into LDS (8 values per thread per chunk, amortised over all Cout columns);
+// weights are split and laid out in fragment order when the layer is registered.
+#include "ovn_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 32;          // K elements per chunk
+constexpr int A_STRIDE = 40;    // bf16 elements per A row in LDS (32 + 8 pad: 80 B = 5 slots, odd -> no conflicts)
+
+struct ConvArgsB {
+  const float* in;
+  const __bf16* wp;   // [nkc][Cout/16][hi,lo][64][8]
+  const float* bias;
+  float* out;
+  int H, W, Cin, OH, OW, Cout, SH, SW;
+  int K, nkc, KWC, rowstride;
+  long long M;
+  int relu;
+};
+
+__device__ __forceinline__ void split_pair_rne(float d0, float d1, unsigned& hi_pk, unsigned& lo_pk) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  bf16x2 h, l;
+  h[0] = (__bf16)d0;
+  h[1] = (__bf16)d1;
+  l[0] = (__bf16)(d0 - (float)h[0]);
+  l[1] = (__bf16)(d1 - (float)h[1]);
+  hi_pk = __builtin_bit_cast(unsigned, h);
+  lo_pk = __builtin_bit_cast(unsigned, l);
+}
+
+__global__ void conv_prep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int K, int nkc, int Cout) {
+  const int NT = Cout / 16;
+  const long long total = (long long)nkc * NT * 512;  // (hi, lo) pairs
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(e & 7);
+    const int lane = (int)((e >> 3) & 63);
+    const long long t = e >> 9;
+    const int nt = (int)(t % NT);
+    const int kc = (int)(t / NT);
+    const int k = kc * KC + 8 * (lane >> 4) + s;
+    const int n = nt * 16 + (lane & 15);
+    const float v = (k < K) ? w[(long long)k * Cout + n] : 0.0f;
+    const __bf16 hi = (__bf16)v;
+    const __bf16 lo = (__bf16)(v - (float)hi);
+    const long long base = (((long long)kc * NT + nt) * 2) * 512 + lane * 8 + s;
+    wp[base] = hi;
+    wp[base + 512] = lo;
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kernel(ConvArgsB a) {
+  constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = 16 * WM * WAVES_M;
+  constexpr int BN = 16 * WN * WAVES_N;
+  constexpr int A_SLOTS = (BM * 4) / NTHREADS;                 // 8-float slots of A per thread per chunk
+  constexpr int B_VEC = BN * 8;                                // 16-byte slots of B per chunk (hi + lo)
+  constexpr int B_PER_THREAD = (B_VEC + NTHREADS - 1) / NTHREADS;
+  static_assert((BM * 4) % NTHREADS == 0, "A tile must divide evenly");
+
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BM * A_STRIDE];
+  __shared__ __attribute__((aligned(16))) __bf16 Al[2][BM * A_STRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * 128];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wave_m = wave / WAVES_N;
+  const int wave_n = wave % WAVES_N;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const long long m0 = (long long)blockIdx.x * BM;
+  const int nt0 = blockIdx.y * (BN / 16);
+  const int NT = a.Cout / 16;
+
+  long long abase[A_SLOTS];
+#pragma unroll
+  for (int r = 0; r < A_SLOTS; ++r) {
+    const int slot = tid + r * NTHREADS;
+    long long m = m0 + (slot >> 2);
+    if (m >= a.M) m = a.M - 1;
+    const int ow = (int)(m % a.OW);
+    const long long t2 = m / a.OW;
+    const int oh = (int)(t2 % a.OH);
+    const long long nb = t2 / a.OH;
+    abase[r] = ((nb * a.H + (long long)oh * a.SH) * a.W + (long long)ow * a.SW) * a.Cin;
+  }
+
+  f32x4 areg[A_SLOTS][2];
+  f32x4 breg[B_PER_THREAD];
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int r = 0; r < A_SLOTS; ++r) {
+      const int slot = tid + r * NTHREADS;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        const int k = kc * KC + 8 * (slot & 3) + 4 * hh;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (VEC4) {
+          if (k < a.K) {
+            const int kh = k / a.KWC;
+            const int x = k - kh * a.KWC;
+            v = *reinterpret_cast<const f32x4*>(a.in + abase[r] + (long long)kh * a.rowstride + x);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kk = k + e;
+            if (kk < a.K) {
+              const int kh = kk / a.KWC;
+              const int x = kk - kh * a.KWC;
+              v[e] = a.in[abase[r] + (long long)kh * a.rowstride + x];
+            }
+          }
+        }
+        areg[r][hh] = v;
+      }
+    }
+    const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wp) + ((long long)kc * NT + nt0) * 2048;
+#pragma unroll
+    for (int r = 0; r < B_PER_THREAD; ++r) {
+      const int slot = tid + r * NTHREADS;
+      if (slot < B_VEC) breg[r] = *reinterpret_cast<const f32x4*>(wsrc + 16 * slot);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int r = 0; r < A_SLOTS; ++r) {
+      const int slot = tid + r * NTHREADS;
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+      split_pair_rne(areg[r][0][0], areg[r][0][1], h0, l0);
+      split_pair_rne(areg[r][0][2], areg[r][0][3], h1, l1);
+      split_pair_rne(areg[r][1][0], areg[r][1][1], h2, l2);
+      split_pair_rne(areg[r][1][2], areg[r][1][3], h3, l3);
+      const int off = (slot >> 2) * A_STRIDE + 8 * (slot & 3);
+      *reinterpret_cast<u32x4*>(&Ah[buf][off]) = (u32x4){h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(&Al[buf][off]) = (u32x4){l0, l1, l2, l3};
+    }
+#pragma unroll
+    for (int r = 0; r < B_PER_THREAD; ++r) {
+      const int slot = tid + r * NTHREADS;
+      if (slot < B_VEC) *reinterpret_cast<f32x4*>(&Bs[buf][16 * slot]) = breg[r];
+    }
+  };
+
+  f32x4 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kc = 0; kc < a.nkc; ++kc) {
+    const bool more = (kc + 1 < a.nkc);
+    if (more) load_chunk(kc + 1);
+
+    bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+      const int off = ((wave_m * WM + i) * 16 + lrow) * A_STRIDE + 8 * g;
+      ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[cur][off]);
+      al[i] = *reinterpret_cast<const bf16x8*>(&Al[cur][off]);
+    }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int off = (((wave_n * WN + j) * 2) * 64 + lane) * 16;
+      bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][off]);
+      bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][off + 1024]);
+    }
+    // term-major so that consecutive MFMAs never chain on the same accumulator
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+
+    if (more) store_chunk(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#pragma unroll
+  for (int j = 0; j < WN; ++j) {
+    const int n = (nt0 + wave_n * WN + j) * 16 + lrow;
+    const float bv = a.bias[n];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long m = m0 + (wave_m * WM + i) * 16 + 4 * g + r;
+        if (m < a.M) {
+          float v = acc[i][j][r] + bv;
+          if (a.relu) v = fmaxf(v, 0.0f);
+          a.out[m * a.Cout + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+int launch_conv_b(const ConvArgsB& a, bool vec4, hipStream_t stream) {
+  constexpr int BM = 16 * WM * WAVES_M;
+  constexpr int BN = 16 * WN * WAVES_N;
+  dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
+  dim3 block(64 * WAVES_M * WAVES_N);
+  if (vec4)
+    hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, 0, stream, a);
+  else
+    hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, 0, stream, a);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+}  // namespace
+
+int ovn_conv_prepare_bf16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream) {
+  OVN_REQUIRE(L->cout % 16 == 0, OVN_ERR_ARG, "layer %s: cout=%d must be a multiple of 16", L->name.c_str(), L->cout);
+  const int K = L->kh * L->kw * L->cin;
+  L->nkc_bf = (K + KC - 1) / KC;
+  const size_t elems = (size_t)L->nkc_bf * (L->cout / 16) * 1024;  // hi + lo
+  OVN_HIP_CHECK(hipMalloc(&L->wp_bf, elems * sizeof(__bf16)));
+  hipLaunchKernelGGL(conv_prep_bf16_kernel, dim3(256), dim3(256), 0, stream, kernel_dev,
+                     reinterpret_cast<__bf16*>(L->wp_bf), K, L->nkc_bf, L->cout);
+  OVN_HIP_CHECK(hipGetLastError());
+  OVN_HIP_CHECK(hipStreamSynchronize(stream));
+  return OVN_OK;
+}
+
+int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh_out,
+                            int* ow_out, hipStream_t stream) {
+  OVN_REQUIRE(L.wp_bf != nullptr && L.bias != nullptr, OVN_ERR_STATE, "layer %s has no bf16x3 weights", L.name.c_str());
+  OVN_REQUIRE(h >= L.kh && w >= L.kw, OVN_ERR_ARG, "layer %s: input %dx%d smaller than kernel", L.name.c_str(), h, w);
+  ConvArgsB a;
+  a.in = in;
+  a.wp = reinterpret_cast<const __bf16*>(L.wp_bf);
+  a.bias = L.bias;
+  a.out = out;
+  a.H = h;
+  a.W = w;
+  a.Cin = L.cin;
+  a.OH = (h - L.kh) / L.sh + 1;
+  a.OW = (w - L.kw) / L.sw + 1;
+  a.Cout = L.cout;
+  a.SH = L.sh;
+  a.SW = L.sw;
+  a.K = L.kh * L.kw * L.cin;
+  a.nkc = L.nkc_bf;
+  a.KWC = L.kw * L.cin;
+  a.rowstride = w * L.cin;
+  a.M = (long long)nb * a.OH * a.OW;
+  a.relu = L.relu;
+  if (oh_out) *oh_out = a.OH;
+  if (ow_out) *ow_out = a.OW;
+  if (a.M == 0) return OVN_OK;
+  const bool vec4 = (L.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  switch (L.cout) {
+    case 16: return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);
+    case 32: return launch_conv_b<2, 2, 4, 1>(a, vec4, stream);
+    case 64: return launch_conv_b<2, 4, 4, 1>(a, vec4, stream);
+    default:
+      if (L.cout % 128 == 0) return launch_conv_b<2, 4, 2, 2>(a, vec4, stream);
+      return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);
+  }
+}

@@ -29,8 +29,10 @@ constexpr int O1 = OVN_C1_OUT;        // 64
 constexpr int O2 = OVN_C2_OUT;        // 128
 constexpr int K2 = S * O1;            // 960
 constexpr int O1_STRIDE = K2 + 8;     // bf16 elements per o1 row in LDS: 1936 B = 121 16-B slots (odd)
-constexpr int NCHUNK = 2 * S;         // W1 half-dj chunks per column group
-constexpr int CHUNK_BYTES = 16384;    // [s(2)][nt(4)][hi/lo][lane(64)][8 bf16]
+constexpr int STEPS_PER_CHUNK = 3;    // MFMA steps per W1 window chunk; 5 chunks = one 15-step channel slice
+constexpr int NCHUNK = 4 * S / STEPS_PER_CHUNK;   // 20 chunks per column group
+constexpr int STEP_BYTES = 8192;      // [nt(4)][hi/lo][lane(64)][8 bf16]
+constexpr int CHUNK_BYTES = STEPS_PER_CHUNK * STEP_BYTES;
 constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + (size_t)S * FC * 4 + 2 * CHUNK_BYTES;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -48,6 +50,18 @@ __device__ __forceinline__ void split_pair(float d0, float d1, unsigned& hi_pk, 
   lp[0] = (__bf16)l0;
   lp[1] = (__bf16)l1;
   lo_pk = __builtin_bit_cast(unsigned, lp);
+}
+
+// A fragments (hi, lo) of one 16-row tile for one MFMA step: 8 values |L - R| per lane.
+__device__ __forceinline__ void make_a(const f32x4& l0, const f32x4& l1, const f32x4& r0, const f32x4& r1, bf16x8& ah,
+                                       bf16x8& al) {
+  unsigned h0, h1, h2, h3, q0, q1, q2, q3;
+  split_pair(l0[0] - r0[0], l0[1] - r0[1], h0, q0);
+  split_pair(l0[2] - r0[2], l0[3] - r0[3], h1, q1);
+  split_pair(l1[0] - r1[0], l1[1] - r1[1], h2, q2);
+  split_pair(l1[2] - r1[2], l1[3] - r1[3], h3, q3);
+  ah = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
+  al = __builtin_bit_cast(bf16x8, (u32x4){q0, q1, q2, q3});
 }
 
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
@@ -93,6 +107,7 @@ __global__ void delta_prep_w2_bf16_kernel(const float* __restrict__ w2, __bf16* 
   }
 }
 
+template <int VARIANT>
 __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __restrict__ feats_l,
                                                                const int32_t* __restrict__ lidx,
                                                                const float* __restrict__ feats_r,
@@ -124,7 +139,7 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
     const int i = 48 * wave + 16 * t + lrow;
     lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
   }
-  f32x4 lcur[3][2], lnext[3][2];
+  f32x4 la[3][2], lb[3][2];  // even / odd channel slices ping-pong (no register rotation)
 #define OVN_LOAD_L(DST, SL)                                                                              \
   _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                        \
     if (lrow_off[t] >= 0) {                                                                              \
@@ -135,19 +150,91 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       DST[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
     }                                                                                                    \
   }
-  OVN_LOAD_L(lcur, 0)
-  OVN_LOAD_L(lnext, 1)
+  OVN_LOAD_L(la, 0)
+  OVN_LOAD_L(lb, 1)
 
-  // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 30 chunks, so the window just wraps)
+  // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 20 chunks, so the window just wraps)
   const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
-  f32x4 pf[2];
-  pf[0] = *reinterpret_cast<const f32x4*>(w1bytes + tid * 16);
-  pf[1] = *reinterpret_cast<const f32x4*>(w1bytes + 8192 + tid * 16);
-  *reinterpret_cast<f32x4*>(wst + tid * 16) = pf[0];
-  *reinterpret_cast<f32x4*>(wst + 8192 + tid * 16) = pf[1];
+  f32x4 pf[STEPS_PER_CHUNK];
+#pragma unroll
+  for (int q = 0; q < STEPS_PER_CHUNK; ++q) {
+    pf[q] = *reinterpret_cast<const f32x4*>(w1bytes + q * STEP_BYTES + tid * 16);
+    *reinterpret_cast<f32x4*>(wst + q * STEP_BYTES + tid * 16) = pf[q];
+  }
   int cur = 0;
-  int sl = 0;  // channel slice of the current step (runs 0,1,2,3,0,... across column groups)
-  int dj = 0;
+  int chunk = 0;  // running chunk index 0..19 within a column group
+
+  // 12 MFMAs of one row tile; term-major so consecutive MFMAs never chain on one accumulator
+#define OVN_TILE_MFMA(T, AH, AL)                                                                          \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bh[nt], acc[T][nt], 0, 0, 0);              \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, bh[nt], acc[T][nt], 0, 0, 0);              \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bl[nt], acc[T][nt], 0, 0, 0);
+  // ask the scheduler for 1 MFMA : 3 VALU in program order (an in-order wave cannot issue VALU past a
+  // matrix-pipe-blocked MFMA, so the split arithmetic of the NEXT tile has to sit between the MFMAs)
+#define OVN_INTERLEAVE()                                                       \
+  _Pragma("unroll") for (int k = 0; k < 12; ++k) {                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
+    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                         \
+  }
+  // One channel slice SL (15 MFMA steps = 5 window chunks) with the L slice held in LX.
+#define OVN_SLICE(LX, SL)                                                                                         \
+  {                                                                                                               \
+    bf16x8 a0h, a0l;                                                                                              \
+    if (VARIANT == 1) {                                                                                           \
+      const float* rr = rs + 32 * g + 8 * (SL);                                                                   \
+      make_a(LX[0][0], LX[0][1], *reinterpret_cast<const f32x4*>(rr), *reinterpret_cast<const f32x4*>(rr + 4),    \
+             a0h, a0l);                                                                                           \
+    }                                                                                                             \
+    for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
+      const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
+      const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
+      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
+          pf[q] = *reinterpret_cast<const f32x4*>(src + q * STEP_BYTES + tid * 16);                               \
+      _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
+        const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
+        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
+        const float* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                     \
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rrow);                                                   \
+        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rrow + 4);                                               \
+        bf16x8 bh[4], bl[4];                                                                                      \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
+          bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                      \
+          bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                      \
+        }                                                                                                         \
+        if (VARIANT == 0) {                                                                                       \
+          _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
+            bf16x8 ah, al;                                                                                        \
+            make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                           \
+            OVN_TILE_MFMA(t, ah, al)                                                                              \
+          }                                                                                                       \
+        } else {                                                                                                  \
+          bf16x8 a1h, a1l, a2h, a2l;                                                                              \
+          make_a(LX[1][0], LX[1][1], r0, r1, a1h, a1l);                                                           \
+          OVN_TILE_MFMA(0, a0h, a0l)                                                                              \
+          OVN_INTERLEAVE()                                                                                        \
+          make_a(LX[2][0], LX[2][1], r0, r1, a2h, a2l);                                                           \
+          OVN_TILE_MFMA(1, a1h, a1l)                                                                              \
+          OVN_INTERLEAVE()                                                                                        \
+          if (dj + 1 < S) {                                                                                       \
+            const float* rn = rrow + FC;                                                                          \
+            make_a(LX[0][0], LX[0][1], *reinterpret_cast<const f32x4*>(rn), *reinterpret_cast<const f32x4*>(rn + 4), \
+                   a0h, a0l);                                                                                     \
+          }                                                                                                       \
+          OVN_TILE_MFMA(2, a2h, a2l)                                                                              \
+          OVN_INTERLEAVE()                                                                                        \
+        }                                                                                                         \
+      }                                                                                                           \
+      unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                        \
+      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
+          *reinterpret_cast<f32x4*>(dstw + q * STEP_BYTES + tid * 16) = pf[q];                                    \
+      __syncthreads();                                                                                            \
+      cur ^= 1;                                                                                                   \
+      chunk = nxt;                                                                                                \
+    }                                                                                                             \
+  }
 
   for (int jb = 0; jb < G; ++jb) {
     __syncthreads();  // previous group's GEMM2 is done with o1h/o1l and rs; W window write above is visible
@@ -161,67 +248,15 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-      const int nxt = (ch + 1 == NCHUNK) ? 0 : ch + 1;
-      const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;
-      pf[0] = *reinterpret_cast<const f32x4*>(src + tid * 16);
-      pf[1] = *reinterpret_cast<const f32x4*>(src + 8192 + tid * 16);
-
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        // one MFMA step: K = 32 channels of R row dj, 3 row tiles x 4 column tiles x 3 split terms
-        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * 8192;
-        const float* rrow = rs + dj * FC + 32 * g + 8 * sl;
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rrow);
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rrow + 4);
-        bf16x8 bh[4], bl[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);
-          bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);
-        }
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          const f32x4 l0 = lcur[t][0], l1 = lcur[t][1];
-          unsigned h0, h1, h2, h3, q0, q1, q2, q3;
-          split_pair(l0[0] - r0[0], l0[1] - r0[1], h0, q0);
-          split_pair(l0[2] - r0[2], l0[3] - r0[3], h1, q1);
-          split_pair(l1[0] - r1[0], l1[1] - r1[1], h2, q2);
-          split_pair(l1[2] - r1[2], l1[3] - r1[3], h3, q3);
-          const u32x4 ahp = {h0, h1, h2, h3};
-          const u32x4 alp = {q0, q1, q2, q3};
-          const bf16x8 ah = __builtin_bit_cast(bf16x8, ahp);
-          const bf16x8 al = __builtin_bit_cast(bf16x8, alp);
-          // consecutive MFMAs hit different accumulators (dependent distance = 4 instructions)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nt], acc[t][nt], 0, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nt], acc[t][nt], 0, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nt], acc[t][nt], 0, 0, 0);
-        }
-        if (++dj == S) {  // slice finished: rotate in the prefetched slice, start fetching the one after
-          dj = 0;
-          sl = (sl + 1) & 3;
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            lcur[t][0] = lnext[t][0];
-            lcur[t][1] = lnext[t][1];
-          }
-          const int sn = (sl + 1) & 3;
-          OVN_LOAD_L(lnext, sn)
-        }
-      }
-
-      unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;
-      *reinterpret_cast<f32x4*>(dstw + tid * 16) = pf[0];
-      *reinterpret_cast<f32x4*>(dstw + 8192 + tid * 16) = pf[1];
-      __syncthreads();
-      cur ^= 1;
-    }
+    // slices 0..3; an L register set is refilled (from L2) as soon as its slice is consumed, 15 steps ahead of use
+    OVN_SLICE(la, 0)
+    OVN_LOAD_L(la, 2)
+    OVN_SLICE(lb, 1)
+    OVN_LOAD_L(lb, 3)
+    OVN_SLICE(la, 2)
+    OVN_LOAD_L(la, 0)
+    OVN_SLICE(lb, 3)
+    OVN_LOAD_L(lb, 1)
 
     // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
 #pragma unroll
@@ -287,6 +322,9 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
 }
 
 #undef OVN_LOAD_L
+#undef OVN_SLICE
+#undef OVN_TILE_MFMA
+#undef OVN_INTERLEAVE
 }  // namespace
 
 int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_dev, void** w1p_out, void** w2p_out,
@@ -303,17 +341,24 @@ int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_
   return OVN_OK;
 }
 
-int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                 const int32_t* ridx, int n, float* o2, hipStream_t stream) {
+template <int VARIANT>
+static int launch_delta_bf16x3(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                               const int32_t* ridx, int n, float* o2, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel),
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel<VARIANT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(delta_c12_bf16x3_kernel, dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
-                     reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
-                     ctx->c2.bias, o2);
+  hipLaunchKernelGGL(delta_c12_bf16x3_kernel<VARIANT>, dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r,
+                     ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1,
+                     reinterpret_cast<const __bf16*>(ctx->w2p_bf), ctx->c2.bias, o2);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
+}
+
+int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                 const int32_t* ridx, int n, float* o2, hipStream_t stream) {
+  if (ctx->delta_variant == 0) return launch_delta_bf16x3<0>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
+  return launch_delta_bf16x3<1>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
 }

@@ -144,6 +144,8 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
   ctx->c3.relu = 1;
   rc = ovn_conv_prepare(&ctx->c3, c3k, c3b, stream);
   if (rc) return rc;
+  rc = ovn_conv_prepare_bf16x3(&ctx->c3, c3k, stream);
+  if (rc) return rc;
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->wd, (size_t)OVN_DENSE_IN * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->bd, sizeof(float)));
   OVN_HIP_CHECK(hipMemcpyAsync(ctx->wd, dk, (size_t)OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice, stream));
@@ -270,7 +272,8 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
     int oh = 0, ow = 0;
     {
       OvnProfScope ps(ctx, OVN_K_C3, stream);
-      rc = ovn_conv_forward(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream);
+      rc = (ctx->head_mode == 0) ? ovn_conv_forward(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream)
+                                 : ovn_conv_forward_bf16x3(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream);
     }
     if (rc) return rc;
     {
@@ -308,8 +311,11 @@ int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, i
 
 int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
-  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
-  ctx->head_mode = mode;
+  OVN_REQUIRE(mode >= 0 && mode <= 3, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  // modes 2/3 = bf16x3 with Delta-kernel schedule variant 0/1 pinned (A/B timing of the two schedules)
+  ctx->head_mode = (mode == 0) ? 0 : 1;
+  if (mode == 2) ctx->delta_variant = 0;
+  if (mode == 3 || mode == 1) ctx->delta_variant = 1;
   return OVN_OK;
 }
 

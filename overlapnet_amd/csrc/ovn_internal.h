@@ -52,6 +52,8 @@ struct OvnConvLayer {
   int nkc = 0;    // ceil(K/16)
   float* wp = nullptr;    // [nkc][cout/16][64][4] fragment-ordered copy (device)
   float* bias = nullptr;  // [cout] (device)
+  void* wp_bf = nullptr;  // optional hi/lo bf16 fragments [ceil(K/32)][cout/16][2][64][8] (conv_bf16x3.hip)
+  int nkc_bf = 0;
 };
 
 struct ovn_ctx {
@@ -68,6 +70,7 @@ struct ovn_ctx {
   OvnConvLayer c3;       // c_conv3 as a regular conv layer
   void* w1p_bf = nullptr;  // c_conv1 hi/lo bf16 fragments (delta_head_bf16x3.hip)
   void* w2p_bf = nullptr;  // c_conv2 hi/lo bf16 fragments
+  int delta_variant = 1;   // schedule variant of the bf16x3 Delta kernel (0 = plain, 1 = software-pipelined split)
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = 3-term bf16 split on the bf16 MFMA
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
@@ -114,6 +117,11 @@ int ovn_conv_prepare(OvnConvLayer* L, const float* kernel_dev, const float* bias
 void ovn_conv_release(OvnConvLayer* L);
 int ovn_conv_forward(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh,
                      int* ow, hipStream_t stream);
+
+// conv_bf16x3.hip
+int ovn_conv_prepare_bf16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream);
+int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh,
+                            int* ow, hipStream_t stream);
 
 // delta_head.hip
 int ovn_delta_prepare_w1(const float* c1_kernel_dev, float** w1p_out, hipStream_t stream);

@@ -232,7 +232,7 @@ class OvnEngine:
 
     def set_head_precision(self, mode: str) -> None:
         """'f32' = fp32 matrix cores, 'bf16x3' = 3-term bf16 split on the bf16 matrix cores (default)."""
-        table = {"f32": 0, "bf16x3": 1}
+        table = {"f32": 0, "bf16x3": 1, "bf16x3_v0": 2, "bf16x3_v1": 3}
         if mode not in table:
             raise ValueError("head precision must be one of %s" % sorted(table))
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
