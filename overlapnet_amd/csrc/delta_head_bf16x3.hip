@@ -183,6 +183,8 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
 #define OVN_SLICE(LX, SL)                                                                                         \
   {                                                                                                               \
     bf16x8 a0h, a0l;                                                                                              \
+    f32x4 rp0 = *reinterpret_cast<const f32x4*>(rs + 32 * g + 8 * (SL));                                          \
+    f32x4 rp1 = *reinterpret_cast<const f32x4*>(rs + 32 * g + 8 * (SL) + 4);                                      \
     if (VARIANT == 1) {                                                                                           \
       const float* rr = rs + 32 * g + 8 * (SL);                                                                   \
       make_a(LX[0][0], LX[0][1], *reinterpret_cast<const f32x4*>(rr), *reinterpret_cast<const f32x4*>(rr + 4),    \
@@ -191,25 +193,61 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
     for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
       const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
       const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
-      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
-          pf[q] = *reinterpret_cast<const f32x4*>(src + q * STEP_BYTES + tid * 16);                               \
+      if (VARIANT != 4 && VARIANT != 9) {                                                                         \
+        _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                               \
+            pf[q] = *reinterpret_cast<const f32x4*>(src + q * STEP_BYTES + tid * 16);                             \
+      }                                                                                                           \
       _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
         const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
-        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
+        const unsigned char* wbuf = (VARIANT == 4) ? w1bytes + ((size_t)chunk * STEPS_PER_CHUNK + h) * STEP_BYTES  \
+                                                   : wst + cur * CHUNK_BYTES + h * STEP_BYTES;                    \
         const float* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                     \
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rrow);                                                   \
-        const f32x4 r1 = *reinterpret_cast<const f32x4*>(rrow + 4);                                               \
+        const f32x4 r0 = rp0, r1 = rp1; /* fetched one step ahead: no LDS round trip at the head of the step */   \
+        if (dj + 1 < S) {                                                                                         \
+          rp0 = *reinterpret_cast<const f32x4*>(rrow + FC);                                                       \
+          rp1 = *reinterpret_cast<const f32x4*>(rrow + FC + 4);                                                   \
+        }                                                                                                         \
         bf16x8 bh[4], bl[4];                                                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
-          bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                      \
-          bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                      \
+          if (VARIANT == 5 || VARIANT == 8 || VARIANT == 9) { /* ablation: B fragments not fetched from LDS */    \
+            u32x4 t0 = __builtin_bit_cast(u32x4, LX[nt & 1][0]), t1 = __builtin_bit_cast(u32x4, LX[nt & 1][1]);   \
+            if (VARIANT != 5) { /* opaque per-step values so nothing is hoisted */                                \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[0]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[1]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[2]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[3]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[0]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[1]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[2]));                                                     \
+              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[3]));                                                     \
+            }                                                                                                     \
+            bh[nt] = __builtin_bit_cast(bf16x8, t0);                                                              \
+            bl[nt] = __builtin_bit_cast(bf16x8, t1);                                                              \
+          } else {                                                                                                \
+            bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                    \
+            bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                    \
+          }                                                                                                       \
         }                                                                                                         \
-        if (VARIANT == 0) {                                                                                       \
+        if (VARIANT == 0 || VARIANT == 4 || VARIANT == 8 || VARIANT == 9) {                                       \
           _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
             bf16x8 ah, al;                                                                                        \
             make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                           \
             OVN_TILE_MFMA(t, ah, al)                                                                              \
           }                                                                                                       \
+        } else if (VARIANT == 2 || VARIANT == 5) { /* ablation: no split arithmetic (WRONG results, timing only) */ \
+          _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
+            const bf16x8 ah = __builtin_bit_cast(bf16x8, LX[t][0]);                                               \
+            const bf16x8 al = __builtin_bit_cast(bf16x8, LX[t][1]);                                               \
+            asm volatile("" ::"v"(r0), "v"(r1));                                                                  \
+            OVN_TILE_MFMA(t, ah, al)                                                                              \
+          }                                                                                                       \
+        } else if (VARIANT == 3) { /* ablation: no MFMA (WRONG results, timing only) */                           \
+          _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
+            bf16x8 ah, al;                                                                                        \
+            make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                           \
+            asm volatile("" ::"v"(ah), "v"(al));                                                                  \
+          }                                                                                                       \
+          _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bh[nt]), "v"(bl[nt]));          \
         } else {                                                                                                  \
           bf16x8 a1h, a1l, a2h, a2l;                                                                              \
           make_a(LX[1][0], LX[1][1], r0, r1, a1h, a1l);                                                           \
@@ -227,11 +265,13 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
           OVN_INTERLEAVE()                                                                                        \
         }                                                                                                         \
       }                                                                                                           \
-      unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                        \
-      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
-          *reinterpret_cast<f32x4*>(dstw + q * STEP_BYTES + tid * 16) = pf[q];                                    \
-      __syncthreads();                                                                                            \
-      cur ^= 1;                                                                                                   \
+      if (VARIANT != 4 && VARIANT != 9) {                                                                         \
+        unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                      \
+        _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                               \
+            *reinterpret_cast<f32x4*>(dstw + q * STEP_BYTES + tid * 16) = pf[q];                                  \
+        __syncthreads();                                                                                          \
+        cur ^= 1;                                                                                                 \
+      }                                                                                                           \
       chunk = nxt;                                                                                                \
     }                                                                                                             \
   }
@@ -249,14 +289,16 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // slices 0..3; an L register set is refilled (from L2) as soon as its slice is consumed, 15 steps ahead of use
-    OVN_SLICE(la, 0)
-    OVN_LOAD_L(la, 2)
-    OVN_SLICE(lb, 1)
-    OVN_LOAD_L(lb, 3)
-    OVN_SLICE(la, 2)
-    OVN_LOAD_L(la, 0)
-    OVN_SLICE(lb, 3)
-    OVN_LOAD_L(lb, 1)
+    if (VARIANT != 7) { /* 7 = ablation: epilogue + GEMM2 only */
+      OVN_SLICE(la, 0)
+      OVN_LOAD_L(la, 2)
+      OVN_SLICE(lb, 1)
+      OVN_LOAD_L(lb, 3)
+      OVN_SLICE(la, 2)
+      OVN_LOAD_L(la, 0)
+      OVN_SLICE(lb, 3)
+      OVN_LOAD_L(lb, 1)
+    }
 
     // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
 #pragma unroll
@@ -359,6 +401,15 @@ static int launch_delta_bf16x3(const ovn_ctx* ctx, const float* feats_l, const i
 
 int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                  const int32_t* ridx, int n, float* o2, hipStream_t stream) {
-  if (ctx->delta_variant == 0) return launch_delta_bf16x3<0>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
-  return launch_delta_bf16x3<1>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
+  switch (ctx->delta_variant) {
+    case 0: return launch_delta_bf16x3<0>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
+    case 2: return launch_delta_bf16x3<2>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
+    case 3: return launch_delta_bf16x3<3>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
+    case 4: return launch_delta_bf16x3<4>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
+    case 8: return launch_delta_bf16x3<8>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
+    case 9: return launch_delta_bf16x3<9>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
+    case 5: return launch_delta_bf16x3<5>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
+    case 7: return launch_delta_bf16x3<7>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
+    default: return launch_delta_bf16x3<1>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
+  }
 }
