@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pool", type=int, default=1024, help="candidate feature volumes resident per GPU")
     ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
-    ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3", "bf16x3_v0", "bf16x3_v1", "abl_nosplit", "abl_nomfma", "bf16x3_v4", "abl_mfmaonly", "abl_gemm2only", "abl_noldsb", "abl_noldsb_nobar"],
+    ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="Delta-head contraction arithmetic: fp32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against the fp64 oracle (untimed)")

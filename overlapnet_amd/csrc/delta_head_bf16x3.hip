@@ -107,7 +107,6 @@ __global__ void delta_prep_w2_bf16_kernel(const float* __restrict__ w2, __bf16* 
   }
 }
 
-template <int VARIANT>
 __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __restrict__ feats_l,
                                                                const int32_t* __restrict__ lidx,
                                                                const float* __restrict__ feats_r,
@@ -172,106 +171,41 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, bh[nt], acc[T][nt], 0, 0, 0);              \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
       acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bl[nt], acc[T][nt], 0, 0, 0);
-  // ask the scheduler for 1 MFMA : 3 VALU in program order (an in-order wave cannot issue VALU past a
-  // matrix-pipe-blocked MFMA, so the split arithmetic of the NEXT tile has to sit between the MFMAs)
-#define OVN_INTERLEAVE()                                                       \
-  _Pragma("unroll") for (int k = 0; k < 12; ++k) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                         \
-    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);                         \
-  }
   // One channel slice SL (15 MFMA steps = 5 window chunks) with the L slice held in LX.
 #define OVN_SLICE(LX, SL)                                                                                         \
   {                                                                                                               \
-    bf16x8 a0h, a0l;                                                                                              \
     f32x4 rp0 = *reinterpret_cast<const f32x4*>(rs + 32 * g + 8 * (SL));                                          \
     f32x4 rp1 = *reinterpret_cast<const f32x4*>(rs + 32 * g + 8 * (SL) + 4);                                      \
-    if (VARIANT == 1) {                                                                                           \
-      const float* rr = rs + 32 * g + 8 * (SL);                                                                   \
-      make_a(LX[0][0], LX[0][1], *reinterpret_cast<const f32x4*>(rr), *reinterpret_cast<const f32x4*>(rr + 4),    \
-             a0h, a0l);                                                                                           \
-    }                                                                                                             \
     for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
       const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
       const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
-      if (VARIANT != 4 && VARIANT != 9) {                                                                         \
-        _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                               \
-            pf[q] = *reinterpret_cast<const f32x4*>(src + q * STEP_BYTES + tid * 16);                             \
-      }                                                                                                           \
+      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
+          pf[q] = *reinterpret_cast<const f32x4*>(src + q * STEP_BYTES + tid * 16);                               \
       _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
         const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
-        const unsigned char* wbuf = (VARIANT == 4) ? w1bytes + ((size_t)chunk * STEPS_PER_CHUNK + h) * STEP_BYTES  \
-                                                   : wst + cur * CHUNK_BYTES + h * STEP_BYTES;                    \
+        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
         const float* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                     \
-        const f32x4 r0 = rp0, r1 = rp1; /* fetched one step ahead: no LDS round trip at the head of the step */   \
+        const f32x4 r0 = rp0, r1 = rp1; /* fetched one step ahead */                                              \
         if (dj + 1 < S) {                                                                                         \
           rp0 = *reinterpret_cast<const f32x4*>(rrow + FC);                                                       \
           rp1 = *reinterpret_cast<const f32x4*>(rrow + FC + 4);                                                   \
         }                                                                                                         \
         bf16x8 bh[4], bl[4];                                                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
-          if (VARIANT == 5 || VARIANT == 8 || VARIANT == 9) { /* ablation: B fragments not fetched from LDS */    \
-            u32x4 t0 = __builtin_bit_cast(u32x4, LX[nt & 1][0]), t1 = __builtin_bit_cast(u32x4, LX[nt & 1][1]);   \
-            if (VARIANT != 5) { /* opaque per-step values so nothing is hoisted */                                \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[0]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[1]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[2]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t0[3]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[0]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[1]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[2]));                                                     \
-              asm volatile("v_mov_b32 %0, %0" : "+v"(t1[3]));                                                     \
-            }                                                                                                     \
-            bh[nt] = __builtin_bit_cast(bf16x8, t0);                                                              \
-            bl[nt] = __builtin_bit_cast(bf16x8, t1);                                                              \
-          } else {                                                                                                \
-            bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                    \
-            bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                    \
-          }                                                                                                       \
+          bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                      \
+          bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                      \
         }                                                                                                         \
-        if (VARIANT == 0 || VARIANT == 4 || VARIANT == 8 || VARIANT == 9) {                                       \
-          _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
-            bf16x8 ah, al;                                                                                        \
-            make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                           \
-            OVN_TILE_MFMA(t, ah, al)                                                                              \
-          }                                                                                                       \
-        } else if (VARIANT == 2 || VARIANT == 5) { /* ablation: no split arithmetic (WRONG results, timing only) */ \
-          _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
-            const bf16x8 ah = __builtin_bit_cast(bf16x8, LX[t][0]);                                               \
-            const bf16x8 al = __builtin_bit_cast(bf16x8, LX[t][1]);                                               \
-            asm volatile("" ::"v"(r0), "v"(r1));                                                                  \
-            OVN_TILE_MFMA(t, ah, al)                                                                              \
-          }                                                                                                       \
-        } else if (VARIANT == 3) { /* ablation: no MFMA (WRONG results, timing only) */                           \
-          _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                         \
-            bf16x8 ah, al;                                                                                        \
-            make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                           \
-            asm volatile("" ::"v"(ah), "v"(al));                                                                  \
-          }                                                                                                       \
-          _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) asm volatile("" ::"v"(bh[nt]), "v"(bl[nt]));          \
-        } else {                                                                                                  \
-          bf16x8 a1h, a1l, a2h, a2l;                                                                              \
-          make_a(LX[1][0], LX[1][1], r0, r1, a1h, a1l);                                                           \
-          OVN_TILE_MFMA(0, a0h, a0l)                                                                              \
-          OVN_INTERLEAVE()                                                                                        \
-          make_a(LX[2][0], LX[2][1], r0, r1, a2h, a2l);                                                           \
-          OVN_TILE_MFMA(1, a1h, a1l)                                                                              \
-          OVN_INTERLEAVE()                                                                                        \
-          if (dj + 1 < S) {                                                                                       \
-            const float* rn = rrow + FC;                                                                          \
-            make_a(LX[0][0], LX[0][1], *reinterpret_cast<const f32x4*>(rn), *reinterpret_cast<const f32x4*>(rn + 4), \
-                   a0h, a0l);                                                                                     \
-          }                                                                                                       \
-          OVN_TILE_MFMA(2, a2h, a2l)                                                                              \
-          OVN_INTERLEAVE()                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                           \
+          bf16x8 ah, al;                                                                                          \
+          make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                             \
+          OVN_TILE_MFMA(t, ah, al)                                                                                \
         }                                                                                                         \
       }                                                                                                           \
-      if (VARIANT != 4 && VARIANT != 9) {                                                                         \
-        unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                      \
-        _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                               \
-            *reinterpret_cast<f32x4*>(dstw + q * STEP_BYTES + tid * 16) = pf[q];                                  \
-        __syncthreads();                                                                                          \
-        cur ^= 1;                                                                                                 \
-      }                                                                                                           \
+      unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                        \
+      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
+          *reinterpret_cast<f32x4*>(dstw + q * STEP_BYTES + tid * 16) = pf[q];                                    \
+      __syncthreads();                                                                                            \
+      cur ^= 1;                                                                                                   \
       chunk = nxt;                                                                                                \
     }                                                                                                             \
   }
@@ -289,16 +223,14 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // slices 0..3; an L register set is refilled (from L2) as soon as its slice is consumed, 15 steps ahead of use
-    if (VARIANT != 7) { /* 7 = ablation: epilogue + GEMM2 only */
-      OVN_SLICE(la, 0)
-      OVN_LOAD_L(la, 2)
-      OVN_SLICE(lb, 1)
-      OVN_LOAD_L(lb, 3)
-      OVN_SLICE(la, 2)
-      OVN_LOAD_L(la, 0)
-      OVN_SLICE(lb, 3)
-      OVN_LOAD_L(lb, 1)
-    }
+    OVN_SLICE(la, 0)
+    OVN_LOAD_L(la, 2)
+    OVN_SLICE(lb, 1)
+    OVN_LOAD_L(lb, 3)
+    OVN_SLICE(la, 2)
+    OVN_LOAD_L(la, 0)
+    OVN_SLICE(lb, 3)
+    OVN_LOAD_L(lb, 1)
 
     // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
 #pragma unroll
@@ -366,7 +298,6 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
 #undef OVN_LOAD_L
 #undef OVN_SLICE
 #undef OVN_TILE_MFMA
-#undef OVN_INTERLEAVE
 }  // namespace
 
 int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_dev, void** w1p_out, void** w2p_out,
@@ -383,33 +314,17 @@ int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_
   return OVN_OK;
 }
 
-template <int VARIANT>
-static int launch_delta_bf16x3(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                               const int32_t* ridx, int n, float* o2, hipStream_t stream) {
+int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                 const int32_t* ridx, int n, float* o2, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel<VARIANT>),
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(delta_c12_bf16x3_kernel<VARIANT>, dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r,
-                     ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1,
-                     reinterpret_cast<const __bf16*>(ctx->w2p_bf), ctx->c2.bias, o2);
+  hipLaunchKernelGGL(delta_c12_bf16x3_kernel, dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
+                     reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
+                     ctx->c2.bias, o2);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
-}
-
-int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                 const int32_t* ridx, int n, float* o2, hipStream_t stream) {
-  switch (ctx->delta_variant) {
-    case 0: return launch_delta_bf16x3<0>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
-    case 2: return launch_delta_bf16x3<2>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
-    case 3: return launch_delta_bf16x3<3>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
-    case 4: return launch_delta_bf16x3<4>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
-    case 8: return launch_delta_bf16x3<8>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
-    case 9: return launch_delta_bf16x3<9>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
-    case 5: return launch_delta_bf16x3<5>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
-    case 7: return launch_delta_bf16x3<7>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);  // ablation
-    default: return launch_delta_bf16x3<1>(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
-  }
 }

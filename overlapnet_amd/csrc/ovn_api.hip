@@ -311,13 +311,8 @@ int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, i
 
 int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
-  OVN_REQUIRE(mode >= 0 && mode <= 11, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
-  // modes 2/3 = bf16x3 with Delta-kernel schedule variant 0/1 pinned (A/B timing of the two schedules)
-  ctx->head_mode = (mode == 0) ? 0 : 1;
-  if (mode == 2) ctx->delta_variant = 0;
-  if (mode >= 4) ctx->delta_variant = mode - 2;  // 4,5 = timing-only ablations (no split / no MFMA), 6 = no LDS window
-  if (mode == 1) ctx->delta_variant = 0;
-  if (mode == 3) ctx->delta_variant = 1;
+  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  ctx->head_mode = mode;
   return OVN_OK;
 }
 

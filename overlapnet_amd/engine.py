@@ -232,7 +232,7 @@ class OvnEngine:
 
     def set_head_precision(self, mode: str) -> None:
         """'f32' = fp32 matrix cores, 'bf16x3' = 3-term bf16 split on the bf16 matrix cores (default)."""
-        table = {"f32": 0, "bf16x3": 1, "bf16x3_v0": 2, "bf16x3_v1": 3, "abl_nosplit": 4, "abl_nomfma": 5, "bf16x3_v4": 6, "abl_mfmaonly": 7, "abl_gemm2only": 9, "abl_noldsb": 10, "abl_noldsb_nobar": 11}
+        table = {"f32": 0, "bf16x3": 1}
         if mode not in table:
             raise ValueError("head precision must be one of %s" % sorted(table))
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
