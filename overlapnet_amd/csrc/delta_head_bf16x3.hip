@@ -267,7 +267,7 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       f32x4 acc2[2];
       acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
+#pragma unroll 6
       for (int ks = 0; ks < K2 / 32; ++ks) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ahp + 32 * ks);
         const bf16x8 al = *reinterpret_cast<const bf16x8*>(alp + 32 * ks);
