@@ -255,40 +255,43 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
     }
     __syncthreads();
 
-    // GEMM2 (24 x 960) x (960 x 128): wave -> m-tile (wave&1), n-tiles 2*(wave>>1), +1
+    // GEMM2 (24 x 960) x (960 x 128): wave w owns output columns 16w..16w+15 for BOTH 16-row m-tiles, so every
+    // W2 fragment is fetched from L2 by exactly one wave of the workgroup (491 KB per column group, not 2x that).
     {
-      const int mt = wave & 1;
-      const int ntp = wave >> 1;
-      int ib = 16 * mt + lrow;
-      if (ib > G - 1) ib = G - 1;
-      const __bf16* ahp = o1h + ib * O1_STRIDE + 8 * g;
-      const __bf16* alp = o1l + ib * O1_STRIDE + 8 * g;
-      const __bf16* wcol = w2p + ((size_t)(2 * ntp) * 2) * 512 + lane * 8;
+      const int ib0 = lrow;                                   // m-tile 0: rows 0..15
+      const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;  // m-tile 1: rows 16..23 (+ 8 padding rows)
+      const __bf16* a0h = o1h + ib0 * O1_STRIDE + 8 * g;
+      const __bf16* a0l = o1l + ib0 * O1_STRIDE + 8 * g;
+      const __bf16* a1h = o1h + ib1 * O1_STRIDE + 8 * g;
+      const __bf16* a1l = o1l + ib1 * O1_STRIDE + 8 * g;
+      const __bf16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;
       f32x4 acc2[2];
       acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 6
       for (int ks = 0; ks < K2 / 32; ++ks) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ahp + 32 * ks);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(alp + 32 * ks);
         const __bf16* wk = wcol + (size_t)ks * (8 * 2 * 512);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wk + (q * 2 + 0) * 512);
-          const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wk + (q * 2 + 1) * 512);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc2[q], 0, 0, 0);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc2[q], 0, 0, 0);
-          acc2[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc2[q], 0, 0, 0);
-        }
+        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wk);
+        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wk + 512);
+        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);
+        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);
+        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);
+        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);
+        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, acc2[1], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, acc2[1], 0, 0, 0);
+        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, acc2[1], 0, 0, 0);
       }
+      const int p = 16 * wave + lrow;
+      const float bv = b2[p];
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int p = 16 * (2 * ntp + q) + lrow;
-        const float bv = b2[p];
+      for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int ib2 = 16 * mt + 4 * g + r;
-          if (ib2 < G) o2[(((long long)pair * G + ib2) * G + jb) * O2 + p] = fmaxf(acc2[q][r] + bv, 0.0f);
+          if (ib2 < G) o2[(((long long)pair * G + ib2) * G + jb) * O2 + p] = fmaxf(acc2[mt][r] + bv, 0.0f);
         }
       }
     }
