@@ -101,6 +101,9 @@ def main():
     ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
     ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="Delta-head contraction arithmetic: fp32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
+    ap.add_argument("--corr", default="spectral", choices=["spectral", "direct"],
+                    help="correlation head: spectral form on cached candidate spectra (default) or direct Gram form")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against the fp64 oracle (untimed)")
     args = ap.parse_args()
@@ -114,8 +117,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     C, P = args.channels, args.pool
@@ -136,19 +141,26 @@ def main():
         eng.leg(torch.from_numpy(np.ascontiguousarray(imgs)).to(dev), out=cands[s:s + n])
     query_img = torch.from_numpy(S.stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], S.flags_of(C))[None]).to(dev)
     query_fv = torch.empty((1, 360, 128), dtype=torch.float32, device=dev)
+    spectral = args.corr == "spectral"
+    cand_spec = eng.spectrum(cands) if spectral else None          # cached per candidate, like its feature volume
+    query_spec = torch.empty((1, 128, eng.SPEC_W), dtype=torch.float32, device=dev) if spectral else None
     torch.cuda.synchronize()
 
     def step():
         eng.leg(query_img, out=query_fv)
-        r = eng.heads(cands, query_fv)
-        if world > 1:
+        if spectral:
+            eng.spectrum(query_fv, out=query_spec)
+            r = eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec)
+        else:
+            r = eng.heads(cands, query_fv)
+        if use_dist:
             return D.gather_scores(r["overlap"], r["yaw"], P * world)
         return r["overlap"], r["yaw"]
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     eng.profile_begin()
     torch.cuda.synchronize()
@@ -156,12 +168,12 @@ def main():
     for _ in range(args.steps):
         res = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -187,7 +199,8 @@ def main():
             "config": {"workload": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
                                    "64x900x%d range images" % (P, P, C),
                        "pairs_per_step": P * world, "channels": C, "weights": "seeded synthetic (no trained weights ship)",
-                       "collective": "gather of (overlap,yaw) to rank 0 per step" if world > 1 else "none"},
+                       "correlation_head": args.corr,
+                       "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": rocprof_traffic(kname.split(" ")[0]),
                          "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * P, "avg_launch_ms": avg_ms, "note": rl_note},
@@ -210,7 +223,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(C, P)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     eng.close()

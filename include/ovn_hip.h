@@ -83,10 +83,25 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l_dev, const int32_t* lidx_dev, c
               const int32_t* ridx_dev, int64_t n, float* overlap_dev, int32_t* yaw_dev, float* logit_dev,
               float* corr_dev, void* stream);
 
+/* Delta (overlap) head alone (generateNet.py:64-116): overlap (n) f32, optional logit (n); indexing as ovn_heads.
+ * Used together with ovn_corr_head_spectral when candidate spectra are cached. */
+int ovn_delta_head(ovn_ctx* ctx, const float* feats_l_dev, const int32_t* lidx_dev, const float* feats_r_dev,
+                   const int32_t* ridx_dev, int64_t n, float* overlap_dev, float* logit_dev, void* stream);
+
 /* Correlation (yaw) head alone (NormalizedCorrelation2D.py:43-109 with normalize='none'); same
  * indexing convention as ovn_heads. */
 int ovn_corr_head(ovn_ctx* ctx, const float* feats_l_dev, const int32_t* lidx_dev, const float* feats_r_dev,
                   const int32_t* ridx_dev, int64_t n, int32_t* yaw_dev, float* corr_dev, void* stream);
+
+/* Spectral form of the correlation head (same result as ovn_corr_head up to fp32 rounding, HBM-bound):
+ * ovn_spectrum turns feature volumes (n, 360, 128) into cached spectra (n, 128, 368) -- per channel the 181
+ * non-redundant DFT bins, real parts at [0..180], imaginary parts at [184..364], zero padding elsewhere;
+ * ovn_corr_head_spectral evaluates corr = IDFT( sum_c L^ conj(R^) ) shifted by W/2 and the argmax for n pairs
+ * (l = spec_l[lidx[p]], r = spec_r[ridx[p]]; NULL index arrays as in ovn_heads).  yaw (n) int32, corr (n,360) or NULL.
+ * Replaces NormalizedCorrelation2D.call (NormalizedCorrelation2D.py:43-109) + infer.py:158 for 1-vs-N sweeps. */
+int ovn_spectrum(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* spectra_dev, void* stream);
+int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l_dev, const int32_t* lidx_dev, const float* spec_r_dev,
+                           const int32_t* ridx_dev, int64_t n, int32_t* yaw_dev, float* corr_dev, void* stream);
 
 /* Spherical projection + normals for a batch of scans (src/utils/utils.py:59-134 range_projection and
  * :137-186 gen_normal_map; the drivers gen_depth_data.py:24-46 etc. loop over files and call these).
@@ -118,7 +133,8 @@ int ovn_set_head_precision(ovn_ctx* ctx, int mode);
  * Between begin and end every kernel group launched through this context is bracketed by an event
  * pair; ovn_profile_end waits for them and returns, per class, the summed milliseconds and the number
  * of bracketed launches.  Classes: 0 leg convolutions (one entry per layer launch), 1 correlation head,
- * 2 fused Delta kernel (DeltaLayer+c_conv1+c_conv2), 3 c_conv3, 4 dense+sigmoid, 5 projection. Arrays of 8. */
+ * 2 fused Delta kernel (DeltaLayer+c_conv1+c_conv2), 3 c_conv3, 4 dense+sigmoid, 5 projection, 6 spectrum (DFT),
+ * 7 spectral correlation head. Arrays of 8. */
 int ovn_profile_begin(ovn_ctx* ctx);
 int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind);
 

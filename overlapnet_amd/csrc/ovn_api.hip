@@ -51,6 +51,13 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
   c->in_h = in_h;
   c->in_w = in_w;
   c->in_c = in_c;
+  int rc = ovn_spectral_prepare(c, nullptr);
+  if (rc) {
+    ovn_conv_release(&c->dft);
+    ovn_conv_release(&c->idft);
+    delete c;
+    return rc;
+  }
   *out = c;
   return OVN_OK;
 }
@@ -62,6 +69,8 @@ int ovn_destroy(ovn_ctx* ctx) {
   for (auto& l : ctx->leg) ovn_conv_release(&l);
   ovn_conv_release(&ctx->c2);
   ovn_conv_release(&ctx->c3);
+  ovn_conv_release(&ctx->dft);
+  ovn_conv_release(&ctx->idft);
   if (ctx->w1p) (void)hipFree(ctx->w1p);
   if (ctx->b1) (void)hipFree(ctx->b1);
   if (ctx->wd) (void)hipFree(ctx->wd);
@@ -230,15 +239,31 @@ int ovn_corr_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const
   return ovn_corr_forward(feats_l, lidx, feats_r, ridx, (int)n, yaw, corr, (hipStream_t)stream);
 }
 
-int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
-              int64_t n, float* overlap, int32_t* yaw, float* logit, float* corr, void* stream_) {
-  OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_heads: head weights not set");
-  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_heads: bad n");
+int ovn_spectrum(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* spectra_dev, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_spectrum: ctx is NULL");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 24), OVN_ERR_ARG, "ovn_spectrum: bad n");
   if (n == 0) return OVN_OK;
-  OVN_REQUIRE(feats_l && feats_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads: NULL buffer");
+  OVN_REQUIRE(feats_dev && spectra_dev, OVN_ERR_ARG, "ovn_spectrum: NULL buffer");
   OVN_HIP_CHECK(hipSetDevice(ctx->device));
-  hipStream_t stream = (hipStream_t)stream_;
+  OvnProfScope ps(ctx, OVN_K_SPECTRUM, (hipStream_t)stream);
+  return ovn_spectrum_forward(ctx, feats_dev, (int)n, spectra_dev, (hipStream_t)stream);
+}
 
+int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,
+                           const int32_t* ridx, int64_t n, int32_t* yaw, float* corr, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_corr_head_spectral: ctx is NULL");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_corr_head_spectral: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(spec_l && spec_r && yaw, OVN_ERR_ARG, "ovn_corr_head_spectral: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OvnProfScope ps(ctx, OVN_K_CORR_SPECTRAL, (hipStream_t)stream);
+  return ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, (hipStream_t)stream);
+}
+
+// Delta (overlap) head on n pairs, chunked over the scratch; shared by ovn_heads and ovn_delta_head.
+static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                          const int32_t* ridx, int64_t n, float* overlap, float* logit, int32_t* yaw, float* corr,
+                          bool with_corr, hipStream_t stream) {
   const size_t o2_elems = (size_t)OVN_G * OVN_G * OVN_C2_OUT;   // 24*24*128 per pair
   const size_t o3_elems = (size_t)OVN_DENSE_IN;                 // 22*22*256 per pair
   const int64_t chunk = 2048;                                   // pairs per pass: 1.6 GB of scratch
@@ -249,7 +274,6 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
   if (rc) return rc;
   float* o2 = reinterpret_cast<float*>(ctx->ws);
   float* o3 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + o2_bytes);
-
   ctx->dbg_o2 = o2;
   ctx->dbg_o3 = o3;
   ctx->dbg_n = cmax;
@@ -258,11 +282,11 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
     const float* fl = lidx ? feats_l : feats_l + (size_t)p0 * OVN_FEAT_ELEMS;
     const int32_t* li = lidx ? lidx + p0 : nullptr;
     const int32_t* ri = ridx ? ridx + p0 : nullptr;
-    {
+    if (with_corr) {
       OvnProfScope ps(ctx, OVN_K_CORR, stream);
       rc = ovn_corr_forward(fl, li, feats_r, ri, np, yaw + p0, corr ? corr + (size_t)p0 * OVN_FEAT_W : nullptr, stream);
+      if (rc) return rc;
     }
-    if (rc) return rc;
     {
       OvnProfScope ps(ctx, OVN_K_DELTA, stream);
       rc = (ctx->head_mode == 0) ? ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream)
@@ -283,6 +307,26 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
     if (rc) return rc;
   }
   return OVN_OK;
+}
+
+int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+              int64_t n, float* overlap, int32_t* yaw, float* logit, float* corr, void* stream_) {
+  OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_heads: head weights not set");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_heads: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(feats_l && feats_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, true, (hipStream_t)stream_);
+}
+
+int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+                   int64_t n, float* overlap, float* logit, void* stream_) {
+  OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_delta_head: head weights not set");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_delta_head: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(feats_l && feats_r && overlap, OVN_ERR_ARG, "ovn_delta_head: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, false, (hipStream_t)stream_);
 }
 
 int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_dev, int n_scans,

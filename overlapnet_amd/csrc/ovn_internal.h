@@ -42,6 +42,8 @@ constexpr int OVN_C2_OUT = 128;   // c_conv2 filters
 constexpr int OVN_C3_OUT = 256;   // c_conv3 filters
 constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
 constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
+constexpr int OVN_SPEC_W = 368;                                 // floats per spectrum row: Re[0..180] | pad | Im at 184.. | pad
+constexpr int OVN_SPEC_ELEMS = OVN_FEAT_C * OVN_SPEC_W;        // 47104 floats = 188,416 B per scan
 
 // ---- a convolution layer in MFMA fragment order ----------------------------------------------------
 struct OvnConvLayer {
@@ -73,6 +75,8 @@ struct ovn_ctx {
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = 3-term bf16 split on the bf16 MFMA
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
+  // spectral correlation head: constant twiddle layers (corr_spectral.hip)
+  OvnConvLayer dft, idft;
   // scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -90,7 +94,8 @@ struct ovn_ctx {
 };
 
 // kernel classes reported by ovn_profile_end
-enum { OVN_K_LEG = 0, OVN_K_CORR = 1, OVN_K_DELTA = 2, OVN_K_C3 = 3, OVN_K_DENSE = 4, OVN_K_PROJ = 5, OVN_K_COUNT = 8 };
+enum { OVN_K_LEG = 0, OVN_K_CORR = 1, OVN_K_DELTA = 2, OVN_K_C3 = 3, OVN_K_DENSE = 4, OVN_K_PROJ = 5, OVN_K_SPECTRUM = 6,
+       OVN_K_CORR_SPECTRAL = 7, OVN_K_COUNT = 8 };
 
 struct OvnProfScope {
   ovn_ctx* ctx;
@@ -138,6 +143,12 @@ int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
                      int n, int32_t* yaw, float* corr, hipStream_t stream);
+
+// corr_spectral.hip
+int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
+int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
+int ovn_corr_spectral_forward(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,
+                              const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream);
 
 // projection.hip
 int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offsets, int n_scans,

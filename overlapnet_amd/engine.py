@@ -119,7 +119,8 @@ class OvnEngine:
         return t
 
     def heads(self, feats_l: torch.Tensor, feats_r: torch.Tensor, lidx=None, ridx=None, n: Optional[int] = None,
-              want_logit: bool = False, want_corr: bool = False):
+              want_logit: bool = False, want_corr: bool = False, spec_l: Optional[torch.Tensor] = None,
+              spec_r: Optional[torch.Tensor] = None):
         """Both heads on n pairs: pair p = (l = feats_l[lidx[p]], r = feats_r[ridx[p]]).
         lidx None -> p, ridx None -> 0 (1-vs-N: feats_r holds the single query).
         Returns dict of device tensors: overlap (n) f32, yaw (n) i32 [, logit (n), corr (n,360)]."""
@@ -143,8 +144,22 @@ class OvnEngine:
             if ri is not None and (int(ri.min()) < 0 or int(ri.max()) >= nr):
                 raise IndexError("right pair index out of range")
         overlap = torch.empty(n, dtype=torch.float32, device=self.device)
-        yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         logit = torch.empty(n, dtype=torch.float32, device=self.device) if want_logit else None
+        if spec_l is not None or spec_r is not None:
+            # cached spectra given: Delta head on the features, correlation head in its HBM-bound spectral form
+            if spec_l is None or spec_r is None:
+                raise _lib.OvnError("spec_l and spec_r must be given together")
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.ovn_delta_head(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n,
+                                                   _ptr(overlap), _ptr(logit), self._stream()), "ovn_delta_head")
+            c = self.corr_head_spectral(spec_l, spec_r, lidx=li, ridx=ri, n=n, want_corr=want_corr)
+            out = {"overlap": overlap, "yaw": c["yaw"]}
+            if want_logit:
+                out["logit"] = logit
+            if want_corr:
+                out["corr"] = c["corr"]
+            return out
+        yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ovn_heads(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n, _ptr(overlap),
@@ -169,6 +184,37 @@ class OvnEngine:
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ovn_corr_head(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n, _ptr(yaw),
                                               _ptr(corr), self._stream()), "ovn_corr_head")
+        return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
+
+    SPEC_W = 368
+
+    def spectrum(self, feats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feature volumes (n,360,128) -> cached spectra (n,128,368) for the spectral correlation head."""
+        self._check_feats(feats, "feats")
+        n = feats.numel() // (FEAT_W * FEAT_C)
+        if out is None:
+            out = torch.empty((n, FEAT_C, self.SPEC_W), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_spectrum(self._h, _ptr(feats), n, _ptr(out), self._stream()), "ovn_spectrum")
+        return out
+
+    def corr_head_spectral(self, spec_l: torch.Tensor, spec_r: torch.Tensor, lidx=None, ridx=None,
+                           n: Optional[int] = None, want_corr: bool = False):
+        """Correlation head on cached spectra: dict(yaw (n) i32 [, corr (n,360)])."""
+        for t, what in ((spec_l, "spec_l"), (spec_r, "spec_r")):
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.OvnError("%s must be a contiguous float32 tensor on %s" % (what, self.device))
+            if t.numel() % (FEAT_C * self.SPEC_W) != 0:
+                raise _lib.OvnError("%s is not a stack of 128x368 spectra" % what)
+        li = self._idx(lidx, None)
+        if n is None:
+            n = li.numel() if li is not None else spec_l.numel() // (FEAT_C * self.SPEC_W)
+        ri = self._idx(ridx, n)
+        yaw = torch.empty(n, dtype=torch.int32, device=self.device)
+        corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_corr_head_spectral(self._h, _ptr(spec_l), _ptr(li), _ptr(spec_r), _ptr(ri), n,
+                                                       _ptr(yaw), _ptr(corr), self._stream()), "ovn_corr_head_spectral")
         return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
 
     # -- preprocessing ------------------------------------------------------------------------------
@@ -238,7 +284,8 @@ class OvnEngine:
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
         self.head_precision = mode
 
-    PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection")
+    PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection", "spectrum",
+                     "corr_spectral")
 
     def profile_begin(self) -> None:
         _lib.check(self.lib.ovn_profile_begin(self._h), "ovn_profile_begin")

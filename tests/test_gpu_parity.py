@@ -342,3 +342,43 @@ def test_infer_class_end_to_end(tmp_path, fixture_npz):
     cfg_bad = dict(cfg, model=dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900], legsType="360OutputkLegs_smaller"))
     with pytest.raises(AttributeError):
         Infer(cfg_bad, weights=w)
+
+
+def test_spectral_correlation_head(engines):
+    """Spectral form of the correlation head (cached spectra) == direct form == fp64 oracle."""
+    rng = np.random.default_rng(41)
+    fv = np.maximum(rng.normal(0.2, 1.0, size=(7, 360, 128)), 0).astype(np.float32)
+    fv[3] = np.roll(fv[0], 25, axis=0)
+    fv[4] *= 0
+    e = engines[4]
+    ft = torch.from_numpy(fv).cuda()
+    spec = e.spectrum(ft)
+    assert tuple(spec.shape) == (7, 128, 368)
+    sp = spec.cpu().numpy()
+    # spectrum == rfft along the column axis, Re at [0..180], Im at [184..364], padding zero
+    ref = np.fft.rfft(fv.astype(np.float64), axis=1)            # (7, 181, 128)
+    assert _rel(sp[:, :, :181], np.transpose(ref.real, (0, 2, 1))) < 5e-6
+    assert _rel(sp[:, :, 184:365], np.transpose(ref.imag, (0, 2, 1))) < 5e-6
+    assert np.all(sp[:, :, 181:184] == 0) and np.all(sp[:, :, 365:] == 0)
+    pairs = np.array([[i, j] for i in range(7) for j in (0, 2, 4)])
+    r = e.corr_head_spectral(spec, spec, lidx=pairs[:, 0], ridx=pairs[:, 1], want_corr=True)
+    d = e.corr_head(ft, ft, lidx=pairs[:, 0], ridx=pairs[:, 1], want_corr=True)
+    fv4 = fv.reshape(-1, 1, 360, 128).astype(np.float64)
+    corr = O.correlation_head_forward(fv4[pairs[:, 0]], fv4[pairs[:, 1]])
+    g = r["corr"].cpu().numpy()
+    scale = np.max(np.abs(corr)) + 1e-30
+    assert np.max(np.abs(g - corr)) / scale < 2e-5, "spectral corr rel err %.3g" % (np.max(np.abs(g - corr)) / scale)
+    yaw = O.yaw_from_orientation(corr)
+    srt = np.sort(corr, axis=1)
+    with np.errstate(all="ignore"):
+        gap = np.nan_to_num((srt[:, -1] - srt[:, -2]) / np.abs(srt[:, -1]))
+    g_yaw = r["yaw"].cpu().numpy()
+    bad = g_yaw != yaw
+    assert not np.any(bad & (gap > 1e-5)), (g_yaw[bad], yaw[bad], gap[bad])
+    assert np.array_equal(g_yaw[gap > 1e-5], d["yaw"].cpu().numpy()[gap > 1e-5])
+    k = [tuple(p) for p in pairs.tolist()]
+    assert g_yaw[k.index((0, 0))] == 0 and g_yaw[k.index((3, 0))] == -25
+    # 1-vs-N convenience form == indexed form
+    a = e.corr_head_spectral(spec, spec[2:3].contiguous())
+    b = e.corr_head_spectral(spec, spec, lidx=np.arange(7), ridx=np.full(7, 2))
+    assert torch.equal(a["yaw"], b["yaw"])
