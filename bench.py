@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
     ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="Delta-head contraction arithmetic: fp32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
+    ap.add_argument("--leg-precision", default="bf16x3", choices=["f32", "bf16x3"],
+                    help="leg convolution arithmetic (the Infer class defaults to f32; both are parity-tested)")
     ap.add_argument("--corr", default="spectral", choices=["spectral", "direct"],
                     help="correlation head: spectral form on cached candidate spectra (default) or direct Gram form")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (path check)")
@@ -128,17 +130,21 @@ def main():
     w = S.make_test_weights(C, seed=0)
     eng.load_weights(w, S.REFERENCE_MODEL_CFG)
     eng.set_head_precision(args.head_precision)
+    eng.set_leg_precision(args.leg_precision)
 
     # ---- untimed setup: candidate pool -> feature volumes resident in HBM (each rank its own pool) ----
     fx = S.load_fixture_images()
     cands = torch.empty((P, 360, 128), dtype=torch.float32, device=dev)
     chunk = 128
+    acc_imgs = None  # host copy of the first candidates' images for the untimed end-to-end accuracy check
     for s in range(0, P, chunk):
         n = min(chunk, P - s)
         imgs = S.candidate_images(n, C, seed=1234 + 7919 * rank + s, fixture=fx)
         # distinct shifts across chunks / ranks
-        imgs = np.roll(imgs, (s * 37 + rank * 11) % 900, axis=2)
-        eng.leg(torch.from_numpy(np.ascontiguousarray(imgs)).to(dev), out=cands[s:s + n])
+        imgs = np.ascontiguousarray(np.roll(imgs, (s * 37 + rank * 11) % 900, axis=2))
+        if s == 0:
+            acc_imgs = imgs[:max(1, min(args.accuracy_pairs, n))].copy()
+        eng.leg(torch.from_numpy(imgs).to(dev), out=cands[s:s + n])
     query_img = torch.from_numpy(S.stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], S.flags_of(C))[None]).to(dev)
     query_fv = torch.empty((1, 360, 128), dtype=torch.float32, device=dev)
     spectral = args.corr == "spectral"
@@ -210,12 +216,16 @@ def main():
         # accuracy part of the metric ("overlap MAE vs ref"): untimed check against the fp64 oracle
         if args.accuracy_pairs > 0:
             from oracle import overlapnet_oracle as O
-            k = min(args.accuracy_pairs, P)
+            k = min(args.accuracy_pairs, acc_imgs.shape[0])
             ov = res[0][:k].float().cpu().numpy()
             yw = res[1][:k].cpu().numpy()
-            fl = cands[:k].cpu().numpy().reshape(k, 1, 360, 128).astype(np.float64)
-            fr = np.repeat(query_fv.cpu().numpy().reshape(1, 1, 360, 128).astype(np.float64), k, axis=0)
+            # end to end: fp64 oracle leg on the same images, then fp64 heads (l = candidate, r = query)
+            all_imgs = np.concatenate([acc_imgs[:k], query_img.cpu().numpy()], axis=0)
+            ofv = O.leg_forward(all_imgs, w, S.REFERENCE_MODEL_CFG, np.float64)
+            fl = ofv[:k]
+            fr = np.repeat(ofv[k:k + 1], k, axis=0)
             o_ov, o_yaw, _, _ = O.heads_forward(fl, fr, w)
+            out["accuracy_scope"] = "images -> leg -> heads vs fp64 oracle"
             out["overlap_mae_vs_oracle"] = float(np.mean(np.abs(ov - o_ov)))
             out["overlap_maxerr_vs_oracle"] = float(np.max(np.abs(ov - o_ov)))
             out["yaw_exact_rate"] = float(np.mean(yw == o_yaw))

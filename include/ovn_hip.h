@@ -129,6 +129,9 @@ int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, i
  *       -- the default; both modes are held to |d overlap| <= 1e-4 against the fp64 oracle by the parity tests. */
 int ovn_set_head_precision(ovn_ctx* ctx, int mode);
 
+/* Arithmetic of the leg convolutions, same two modes as ovn_set_head_precision (default 0 = fp32 matrix cores). */
+int ovn_set_leg_precision(ovn_ctx* ctx, int mode);
+
 /* Per-kernel-class timing with HIP events recorded on the launch stream, for bench.py's roofline line.
  * Between begin and end every kernel group launched through this context is bracketed by an event
  * pair; ovn_profile_end waits for them and returns, per class, the summed milliseconds and the number

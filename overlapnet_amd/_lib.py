@@ -38,6 +38,7 @@ SIGNATURES = {
                               C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ovn_normals": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ovn_set_head_precision": (C.c_int, [_vp, C.c_int]),
+    "ovn_set_leg_precision": (C.c_int, [_vp, C.c_int]),
     "ovn_profile_begin": (C.c_int, [_vp]),
     "ovn_profile_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ovn_debug_conv": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),

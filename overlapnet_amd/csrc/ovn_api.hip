@@ -102,6 +102,11 @@ int ovn_add_leg_layer(ovn_ctx* ctx, const char* name, const float* kernel_dev, c
   L.relu = 1;  // every leg layer is Conv2D(..., activation='relu'), generateNet.py:161-214
   int rc = ovn_conv_prepare(&L, kernel_dev, bias_dev, (hipStream_t)stream);
   if (rc) return rc;
+  rc = ovn_conv_prepare_bf16x3(&L, kernel_dev, (hipStream_t)stream);
+  if (rc) {
+    ovn_conv_release(&L);
+    return rc;
+  }
   ctx->leg.push_back(L);
   return OVN_OK;
 }
@@ -217,7 +222,8 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       int oh = 0, ow = 0;
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
-        rc = ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream);
+        rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
+                                  : ovn_conv_forward_bf16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream);
       }
       if (rc) return rc;
       cur = dst;
@@ -357,6 +363,13 @@ int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
   OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
   ctx->head_mode = mode;
+  return OVN_OK;
+}
+
+int ovn_set_leg_precision(ovn_ctx* ctx, int mode) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_leg_precision: ctx is NULL");
+  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_leg_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  ctx->leg_mode = mode;
   return OVN_OK;
 }
 

@@ -44,6 +44,7 @@ class OvnEngine:
         self._leg_ready = False
         self._head_ready = False
         self.head_precision = "bf16x3"
+        self.leg_precision = "f32"
 
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:
@@ -283,6 +284,14 @@ class OvnEngine:
             raise ValueError("head precision must be one of %s" % sorted(table))
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
         self.head_precision = mode
+
+    def set_leg_precision(self, mode: str) -> None:
+        """'f32' (default) = fp32 matrix cores, 'bf16x3' = 3-term bf16 split for the leg convolutions."""
+        table = {"f32": 0, "bf16x3": 1}
+        if mode not in table:
+            raise ValueError("leg precision must be one of %s" % sorted(table))
+        _lib.check(self.lib.ovn_set_leg_precision(self._h, table[mode]), "ovn_set_leg_precision")
+        self.leg_precision = mode
 
     PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection", "spectrum",
                      "corr_spectral")

@@ -105,6 +105,31 @@ def test_leg_against_oracle_and_golden(engines, fixture_images, nn_golden, C):
     assert np.all(np.abs(ref[mism]) < 1e-5 * np.max(ref))
 
 
+@pytest.mark.parametrize("C", [1, 4, 5])
+def test_leg_bf16x3_mode(engines, fixture_images, C):
+    """Leg convolutions on the bf16 matrix cores with the 3-term split: features within 5e-5 of the fp64 oracle
+    (fp32 mode: 2e-5), and the end-to-end overlap/yaw gates still hold on features produced this way."""
+    imgs = np.concatenate([fixture_images(C), S.candidate_images(4, C, seed=9)[2:]])
+    w = S.make_test_weights(C, seed=0)
+    e = engines[C]
+    e.set_leg_precision("bf16x3")
+    try:
+        fv = e.leg(torch.from_numpy(imgs).cuda())
+    finally:
+        e.set_leg_precision("f32")
+    ref = O.leg_forward(imgs, w, CFG, np.float64)
+    err = _rel(fv.cpu().numpy(), ref.reshape(-1, 360, 128))
+    assert err < 5e-5, "bf16x3 leg rel err %.3g" % err
+    pairs = np.array([[0, 1], [1, 0], [2, 0], [3, 1], [2, 3]])
+    r = e.heads(fv, fv, lidx=pairs[:, 0], ridx=pairs[:, 1])
+    ov, yaw, _, corr = O.heads_forward(ref[pairs[:, 0]], ref[pairs[:, 1]], w)
+    assert np.max(np.abs(r["overlap"].cpu().numpy() - ov)) <= 1e-4
+    srt = np.sort(corr, axis=1)
+    gap = (srt[:, -1] - srt[:, -2]) / np.abs(srt[:, -1])
+    bad = r["yaw"].cpu().numpy() != yaw
+    assert not np.any(bad & (gap > 1e-4)), (r["yaw"].cpu().numpy(), yaw, gap)
+
+
 def test_leg_batch_tail_and_slicing(engines, fixture_images):
     """n not a multiple of any tile, and > the internal 256-scan slice: same result per scan."""
     imgs = fixture_images(4)
