@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
     ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="Delta-head contraction arithmetic: fp32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
+    ap.add_argument("--mode", default="warm", choices=["warm", "cold", "fullstack"],
+                    help="warm (default, the BASELINE metric): candidate features cached, step = query leg + heads; "
+                         "cold: step also runs the legs of all candidates from images resident in HBM; "
+                         "fullstack: step starts from raw point clouds (projection + normals on the GPU)")
     ap.add_argument("--leg-precision", default="bf16x3", choices=["f32", "bf16x3"],
                     help="leg convolution arithmetic (the Infer class defaults to f32; both are parity-tested)")
     ap.add_argument("--corr", default="spectral", choices=["spectral", "direct"],
@@ -135,6 +139,7 @@ def main():
     # ---- untimed setup: candidate pool -> feature volumes resident in HBM (each rank its own pool) ----
     fx = S.load_fixture_images()
     cands = torch.empty((P, 360, 128), dtype=torch.float32, device=dev)
+    cold_imgs = torch.empty((P, 64, 900, C), dtype=torch.float32, device=dev) if args.mode == "cold" else None
     chunk = 128
     acc_imgs = None  # host copy of the first candidates' images for the untimed end-to-end accuracy check
     for s in range(0, P, chunk):
@@ -144,15 +149,52 @@ def main():
         imgs = np.ascontiguousarray(np.roll(imgs, (s * 37 + rank * 11) % 900, axis=2))
         if s == 0:
             acc_imgs = imgs[:max(1, min(args.accuracy_pairs, n))].copy()
-        eng.leg(torch.from_numpy(imgs).to(dev), out=cands[s:s + n])
+        timg = torch.from_numpy(imgs).to(dev)
+        if cold_imgs is not None:
+            cold_imgs[s:s + n].copy_(timg)
+        eng.leg(timg, out=cands[s:s + n])
     query_img = torch.from_numpy(S.stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], S.flags_of(C))[None]).to(dev)
     query_fv = torch.empty((1, 360, 128), dtype=torch.float32, device=dev)
+    raw = None
+    if args.mode == "fullstack":
+        # raw scans resident in HBM: the two shipped KITTI scans rotated about z by i * 360/P degrees
+        base = [torch.from_numpy(fx["points_%d" % i]).to(dev) for i in range(2)]
+        pts, offs = [], [0]
+        for i in range(P + 1):
+            b = base[i % 2]
+            th = 2.0 * np.pi * ((i * 37) % 900) / 900.0
+            c_, s_ = float(np.cos(th)), float(np.sin(th))
+            q = b.clone()
+            q[:, 0] = c_ * b[:, 0] - s_ * b[:, 1]
+            q[:, 1] = s_ * b[:, 0] + c_ * b[:, 1]
+            pts.append(q)
+            offs.append(offs[-1] + q.shape[0])
+        raw = (torch.cat(pts).contiguous(), torch.tensor(offs, dtype=torch.int64, device=dev), max(p.shape[0] for p in base))
+        del pts
+    flags = S.flags_of(C)
+    all_fv = torch.empty((P + 1, 360, 128), dtype=torch.float32, device=dev) if args.mode != "warm" else None
     spectral = args.corr == "spectral"
     cand_spec = eng.spectrum(cands) if spectral else None          # cached per candidate, like its feature volume
     query_spec = torch.empty((1, 128, eng.SPEC_W), dtype=torch.float32, device=dev) if spectral else None
     torch.cuda.synchronize()
 
-    def step():
+    def step_cold():
+        if raw is not None:
+            imgs_dev = eng.project(raw[0], raw[1], raw[2], want=(), stacked_flags=flags)["stacked"]
+        else:
+            imgs_dev = torch.cat([cold_imgs, query_img])
+        eng.leg(imgs_dev, out=all_fv)
+        cf, qf = all_fv[:P], all_fv[P:]
+        if spectral:
+            sp = eng.spectrum(all_fv)
+            r = eng.heads(cf, qf, spec_l=sp[:P], spec_r=sp[P:])
+        else:
+            r = eng.heads(cf, qf)
+        if use_dist:
+            return D.gather_scores(r["overlap"], r["yaw"], P * world)
+        return r["overlap"], r["yaw"]
+
+    def step_warm():
         eng.leg(query_img, out=query_fv)
         if spectral:
             eng.spectrum(query_fv, out=query_spec)
@@ -163,6 +205,7 @@ def main():
             return D.gather_scores(r["overlap"], r["yaw"], P * world)
         return r["overlap"], r["yaw"]
 
+    step = step_warm if args.mode == "warm" else step_cold
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -202,8 +245,13 @@ def main():
             "metric": "scan-pairs/s (64x900 range images)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
-                                   "64x900x%d range images" % (P, P, C),
+            "config": {"workload": {"warm": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
+                                            "64x900x%d range images" % (P, P, C),
+                                    "cold": "1-vs-%d sweep per GPU, COLD: %d legs from images in HBM + %d head pairs per step, "
+                                            "64x900x%d" % (P, P + 1, P, C),
+                                    "fullstack": "1-vs-%d sweep per GPU from RAW scans: projection+normals of %d clouds, %d legs, "
+                                                 "%d head pairs per step, 64x900x%d" % (P, P + 1, P + 1, P, C)}[args.mode],
+                       "mode": args.mode,
                        "pairs_per_step": P * world, "channels": C, "weights": "seeded synthetic (no trained weights ship)",
                        "correlation_head": args.corr,
                        "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
