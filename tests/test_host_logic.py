@@ -1,0 +1,101 @@
+"""CPU: host-side logic that needs no GPU -- weight containers, synthetic generators, loop-closure gating, metrics."""
+import os
+
+import numpy as np
+import pytest
+
+from overlapnet_amd import evaluate as E
+from overlapnet_amd import lcd
+from overlapnet_amd import synthetic as S
+from overlapnet_amd import weights as W
+
+
+def test_weight_container_roundtrip_and_checks(tmp_path):
+    w = S.make_test_weights(4, seed=3)
+    W.check_weights(w, 4, S.REFERENCE_MODEL_CFG)
+    p = str(tmp_path / "w.npz")
+    W.save_npz(p, w)
+    w2 = W.load_weights_file(p)
+    assert sorted(w2) == sorted(w) and all(np.array_equal(w[k], w2[k]) for k in w)
+    assert len(w) == 30  # 15 layers x (kernel, bias): s_conv1..10 + s_conv3a, c_conv1..3, overlap_output
+    bad = dict(w)
+    bad.pop("s_conv3a/kernel")
+    with pytest.raises(KeyError):
+        W.check_weights(bad, 4, S.REFERENCE_MODEL_CFG)
+    bad = dict(w, **{"c_conv1/kernel": np.zeros((1, 15, 128, 32), np.float32)})
+    with pytest.raises(ValueError):
+        W.check_weights(bad, 4, S.REFERENCE_MODEL_CFG)
+    with pytest.raises(Exception, match="not found"):
+        W.load_weights_file(str(tmp_path / "missing.weight"))
+    junk = tmp_path / "junk.weight"
+    junk.write_bytes(b"not a weight file")
+    with pytest.raises(Exception, match="unrecognised"):
+        W.load_weights_file(str(junk))
+    # Keras default init: glorot-uniform kernels within their limit, zero biases (what infer.py:121-122 leaves)
+    k = W.keras_default_init(4, S.REFERENCE_MODEL_CFG, seed=1)
+    lim = np.sqrt(6.0 / (5 * 15 * 4 + 5 * 15 * 16))
+    assert np.all(np.abs(k["s_conv1/kernel"]) <= lim) and np.all(k["s_conv1/bias"] == 0)
+
+
+def test_synthetic_inputs_are_deterministic_and_shaped():
+    a = S.candidate_images(5, 4, seed=11)
+    b = S.candidate_images(5, 4, seed=11)
+    assert a.shape == (5, 64, 900, 4) and a.dtype == np.float32 and np.array_equal(a, b)
+    fx = S.load_fixture_images()
+    # candidate 0 is fixture scan 0 unshifted: invalid mask preserved, only valid depths perturbed
+    assert np.array_equal(a[0, ..., 0] == -1, fx["range_0"] == -1)
+    assert np.array_equal(a[0, ..., 1:4], fx["normal_0"])
+    valid = fx["range_0"] > 0
+    assert np.max(np.abs(a[0, ..., 0][valid] - fx["range_0"][valid])) < 0.2
+    # candidate 3 = fixture 1 shifted by 111 columns
+    assert np.array_equal(a[3, ..., 1:4], np.roll(fx["normal_1"], 111, axis=1))
+    assert S.flags_of(5) == (True, True, True) and S.channels_of(True, True, False) == 4
+    with pytest.raises(ValueError):
+        S.flags_of(7)
+
+
+def test_loop_closure_gating_and_decision():
+    # straight drive out along x, a sideways loop, and a return next to the start
+    t = np.arange(400)
+    xy = np.stack([np.where(t < 200, t * 1.0, 399.0 - t), np.where(t < 200, 0.0, 2.0)], axis=1)
+    tl = lcd.travelled_distances(xy)
+    assert tl[0] == 0 and abs(tl[199] - 199.0) < 1e-9
+    ell = lcd.covariance_ellipse(np.diag([9.0, 4.0]), nstd=3.0)
+    assert abs(ell[0] - 18.0) < 1e-9 and abs(ell[1] - 12.0) < 1e-9
+    assert lcd.gate_candidates(50, xy, tl, ell).size == 0          # younger than the inactive window
+    ref = lcd.gate_candidates(390, xy, tl, ell)                     # near x = 9 on the way back
+    assert ref.size > 0 and np.all(ref < 290)
+    assert np.all(np.abs(xy[ref, 0] - xy[390, 0]) <= 9.0 + 1e-9)   # inside the 3-sigma half-width along x
+    assert np.all(tl[390] - tl[ref] > 50.0)
+    assert lcd.decide(ref, np.full(ref.size, 0.1), np.zeros(ref.size, int)) is None
+    ov = np.linspace(0.2, 0.9, ref.size)
+    d = lcd.decide(ref, ov, np.arange(ref.size))
+    assert d == (int(ref[-1]), float(ov[-1]), ref.size - 1)
+    assert lcd.decide([], [], []) is None
+
+    class FakeInfer:
+        def __init__(self):
+            self.calls = []
+
+        def infer_multiple(self, cur, refs):
+            self.calls.append((cur, list(refs)))
+            if not refs:
+                return None
+            return np.linspace(0.2, 0.9, len(refs)), np.zeros(len(refs), int)
+
+    f = FakeInfer()
+    assert lcd.detect(f, 10, xy, tl, ell) is None and f.calls[-1] == (10, [])
+    got = lcd.detect(f, 390, xy, tl, ell)
+    assert got is not None and got[0] == int(ref[-1]) and f.calls[-1][0] == 390
+
+
+def test_error_statistics(tmp_path):
+    gt = np.array([[0, 1, 0.9, 180], [0, 2, 0.2, 170], [1, 2, 0.8, 5]], float)
+    np.savez(tmp_path / "gt.npz", overlaps=gt, seq=np.array([["07", "07"]] * 3, dtype=object))
+    i1, i2, ov, yb = E.load_ground_truth(str(tmp_path / "gt.npz"))
+    assert list(i2) == [1, 2, 2] and list(yb) == [180, 170, 5]
+    assert list(E.yaw_bin_to_degrees(yb)) == [0, 10, 175]
+    assert list(E.circular_error_deg([179, -179, 0], [-179, 179, 10])) == [2, 2, 10]
+    st = E.error_statistics([0.85, 0.3, 0.7], ov, [0, 0, -178], E.yaw_bin_to_degrees(yb))
+    assert st["n"] == 3 and abs(st["overlap_mae"] - (0.05 + 0.1 + 0.1) / 3) < 1e-12 and abs(st["overlap_max"] - 0.1) < 1e-12
+    assert st["yaw_n"] == 2 and st["yaw_max_err_deg"] == 7 and abs(st["yaw_mean_err_deg"] - 3.5) < 1e-12
