@@ -15,6 +15,8 @@
 // (24 VGPRs instead of 96; the next slice is prefetched from L2 while the current one is consumed).
 // |L-R| is formed and split on the VALU while the matrix pipe works on the previous step.  W1 (hi and lo, pre-permuted to this order) streams through a double-buffered
 // 2 x 16 KB LDS window shared by the 8 waves; o1 goes to LDS as hi/lo bf16 in GEMM2's [24][960] A layout.
+#include <stdlib.h>
+
 #include "ovn_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -107,14 +109,15 @@ __global__ void delta_prep_w2_bf16_kernel(const float* __restrict__ w2, __bf16* 
   }
 }
 
-__global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __restrict__ feats_l,
+template <int T, int NW>
+__global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* __restrict__ feats_l,
                                                                const int32_t* __restrict__ lidx,
                                                                const float* __restrict__ feats_r,
                                                                const int32_t* __restrict__ ridx,
                                                                const __bf16* __restrict__ w1p,
                                                                const float* __restrict__ b1,
                                                                const __bf16* __restrict__ w2p,
-                                                               const float* __restrict__ b2, float* __restrict__ o2) {
+                                                               const float* __restrict__ b2, float* __restrict__ o2, int rot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* o1h = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* o1l = o1h + G * O1_STRIDE;
@@ -132,15 +135,18 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
   const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
 
   // this lane's slice of L for channel slice s: rows 48*wave + 16*t + lrow, channels 32g + 8s .. +7
-  int lrow_off[3];
+  constexpr int NT_ = 64 * NW;                       // threads
+  constexpr int PFN = CHUNK_BYTES / (NT_ * 16);      // 16-byte window pieces per thread per chunk
+  static_assert(CHUNK_BYTES % (NT_ * 16) == 0 && T * NW * 16 >= FW, "bad tiling");
+  int lrow_off[T];
 #pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int i = 48 * wave + 16 * t + lrow;
+  for (int t = 0; t < T; ++t) {
+    const int i = 16 * T * wave + 16 * t + lrow;
     lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
   }
-  f32x4 la[3][2], lb[3][2];  // even / odd channel slices ping-pong (no register rotation)
+  f32x4 la[T][2], lb[T][2];  // even / odd channel slices ping-pong (no register rotation)
 #define OVN_LOAD_L(DST, SL)                                                                              \
-  _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                        \
+  _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
     if (lrow_off[t] >= 0) {                                                                              \
       DST[t][0] = *reinterpret_cast<const f32x4*>(L + lrow_off[t] + 8 * (SL));                           \
       DST[t][1] = *reinterpret_cast<const f32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                       \
@@ -149,19 +155,24 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       DST[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};                                                           \
     }                                                                                                    \
   }
-  OVN_LOAD_L(la, 0)
-  OVN_LOAD_L(lb, 1)
+  // Workgroups walk the channel slices (and with them the W1 stream) in rotated order: the 32 CUs of an XCD then
+  // touch every W1 line several times per column-group period instead of in one burst, which keeps the 1 MB of
+  // weights resident in the 4 MB L2 under the private L / o2 streams (LRU thrash otherwise: 18.7 GB/launch of misses).
+  const int s0 = rot ? ((blockIdx.x >> 3) & 3) : 0;
+  const int s1 = (s0 + 1) & 3, s2 = (s0 + 2) & 3, s3 = (s0 + 3) & 3;
+  OVN_LOAD_L(la, s0)
+  OVN_LOAD_L(lb, s1)
 
   // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 20 chunks, so the window just wraps)
   const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
-  f32x4 pf[STEPS_PER_CHUNK];
+  f32x4 pf[PFN];
 #pragma unroll
-  for (int q = 0; q < STEPS_PER_CHUNK; ++q) {
-    pf[q] = *reinterpret_cast<const f32x4*>(w1bytes + q * STEP_BYTES + tid * 16);
-    *reinterpret_cast<f32x4*>(wst + q * STEP_BYTES + tid * 16) = pf[q];
+  for (int q = 0; q < PFN; ++q) {
+    pf[q] = *reinterpret_cast<const f32x4*>(w1bytes + (size_t)(5 * s0) * CHUNK_BYTES + (q * NT_ + tid) * 16);
+    *reinterpret_cast<f32x4*>(wst + (q * NT_ + tid) * 16) = pf[q];
   }
   int cur = 0;
-  int chunk = 0;  // running chunk index 0..19 within a column group
+  int chunk = 5 * s0;  // running chunk index 0..19 (cyclic), 5 chunks per slice
 
   // 12 MFMAs of one row tile; term-major so consecutive MFMAs never chain on one accumulator
 #define OVN_TILE_MFMA(T, AH, AL)                                                                          \
@@ -179,8 +190,8 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
     for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
       const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
       const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
-      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
-          pf[q] = *reinterpret_cast<const f32x4*>(src + q * STEP_BYTES + tid * 16);                               \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
+          pf[q] = *reinterpret_cast<const f32x4*>(src + (q * NT_ + tid) * 16);                                    \
       _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
         const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
         const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
@@ -195,15 +206,15 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
           bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                      \
           bl[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                      \
         }                                                                                                         \
-        _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                           \
+        _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                           \
           bf16x8 ah, al;                                                                                          \
           make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                             \
           OVN_TILE_MFMA(t, ah, al)                                                                                \
         }                                                                                                         \
       }                                                                                                           \
       unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                        \
-      _Pragma("unroll") for (int q = 0; q < STEPS_PER_CHUNK; ++q)                                                 \
-          *reinterpret_cast<f32x4*>(dstw + q * STEP_BYTES + tid * 16) = pf[q];                                    \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
+          *reinterpret_cast<f32x4*>(dstw + (q * NT_ + tid) * 16) = pf[q];                                         \
       __syncthreads();                                                                                            \
       cur ^= 1;                                                                                                   \
       chunk = nxt;                                                                                                \
@@ -216,21 +227,21 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       *reinterpret_cast<f32x4*>(rs + 4 * tid) = *reinterpret_cast<const f32x4*>(R + jb * S * FC + 4 * tid);
     __syncthreads();
 
-    f32x4 acc[3][4];
+    f32x4 acc[T][4];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < T; ++t)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // slices 0..3; an L register set is refilled (from L2) as soon as its slice is consumed, 15 steps ahead of use
-    OVN_SLICE(la, 0)
-    OVN_LOAD_L(la, 2)
-    OVN_SLICE(lb, 1)
-    OVN_LOAD_L(lb, 3)
-    OVN_SLICE(la, 2)
-    OVN_LOAD_L(la, 0)
-    OVN_SLICE(lb, 3)
-    OVN_LOAD_L(lb, 1)
+    OVN_SLICE(la, s0)
+    OVN_LOAD_L(la, s2)
+    OVN_SLICE(lb, s1)
+    OVN_LOAD_L(lb, s3)
+    OVN_SLICE(la, s2)
+    OVN_LOAD_L(la, s0)
+    OVN_SLICE(lb, s3)
+    OVN_LOAD_L(lb, s1)
 
     // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
 #pragma unroll
@@ -238,10 +249,10 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       const int o = 16 * nt + lrow;
       const float bv = b1[o];
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < T; ++t) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int i = 48 * wave + 16 * t + 4 * g + r;
+          const int i = 16 * T * wave + 16 * t + 4 * g + r;
           if (i < FW) {
             const int ib = i / S;
             const int di = i - ib * S;
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
 
     // GEMM2 (24 x 960) x (960 x 128): wave w owns output columns 16w..16w+15 for BOTH 16-row m-tiles, so every
     // W2 fragment is fetched from L2 by exactly one wave of the workgroup (491 KB per column group, not 2x that).
-    {
+    if (wave < 8) {
       const int ib0 = lrow;                                   // m-tile 0: rows 0..15
       const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;  // m-tile 1: rows 16..23 (+ 8 padding rows)
       const __bf16* a0h = o1h + ib0 * O1_STRIDE + 8 * g;
@@ -268,8 +279,11 @@ __global__ __launch_bounds__(512) void delta_c12_bf16x3_kernel(const float* __re
       f32x4 acc2[2];
       acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
 #pragma unroll 6
-      for (int ks = 0; ks < K2 / 32; ++ks) {
+      for (int kk = 0; kk < K2 / 32; ++kk) {
+        int ks = kk + ks0;
+        if (ks >= K2 / 32) ks -= K2 / 32;
         const __bf16* wk = wcol + (size_t)ks * (8 * 2 * 512);
         const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wk);
         const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wk + 512);
@@ -319,15 +333,32 @@ int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_
 
 int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                  const int32_t* ridx, int n, float* o2, hipStream_t stream) {
+  static int rot = -1;
+  if (rot < 0) {
+    const char* e = getenv("OVN_DELTA_ROT");
+    rot = e ? atoi(e) : 1;
+  }
+  static int sched = -1;  // 0: 8 waves x 3 row tiles (2 waves/SIMD), 1: 12 waves x 2 row tiles (3 waves/SIMD)
+  if (sched < 0) {
+    const char* e = getenv("OVN_DELTA_SCHED");
+    sched = e ? atoi(e) : 0;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel),
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel<3, 8>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel<2, 12>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL(delta_c12_bf16x3_kernel, dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
-                     reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
-                     ctx->c2.bias, o2);
+  if (sched == 1)
+    hipLaunchKernelGGL((delta_c12_bf16x3_kernel<2, 12>), dim3(n), dim3(768), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
+                       reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
+                       ctx->c2.bias, o2, rot);
+  else
+    hipLaunchKernelGGL((delta_c12_bf16x3_kernel<3, 8>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
+                       reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
+                       ctx->c2.bias, o2, rot);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
