@@ -245,10 +245,21 @@ def test_one_vs_n_equals_indexed_pairs_and_is_deterministic(engines):
     allf = torch.cat([query, cands])
     c = e.heads(allf, allf, lidx=np.arange(1, n + 1), ridx=np.zeros(n, np.int64), want_logit=True)
     assert torch.equal(a["logit"], c["logit"]) and torch.equal(a["yaw"], c["yaw"]) and torch.equal(a["overlap"], c["overlap"])
-    # periodic inputs -> periodic outputs (every candidate of the same residue class agrees exactly)
+    # periodic inputs -> periodic outputs.  The bf16x3 Delta kernel rotates its K walk with the workgroup index (L2
+    # locality), so the same pair at another batch position sees its split rounding errors summed in another order: a few 1e-6 on
+    # the logit, an order of magnitude inside the bf16x3 error budget against the oracle; the
+    # fp32 mode keeps one fixed order and is bit-identical at every position.
     lg = a["logit"].cpu().numpy()
+    yw = a["yaw"].cpu().numpy()
     for r in range(5):
-        assert np.all(lg[r::5] == lg[r])
+        assert np.all(np.abs(lg[r::5] - lg[r]) <= 2e-5 * (1 + abs(lg[r]))) and np.all(yw[r::5] == yw[r])
+    e.set_head_precision("f32")
+    try:
+        f = e.heads(cands, query, want_logit=True)["logit"].cpu().numpy()
+    finally:
+        e.set_head_precision("bf16x3")
+    for r in range(5):
+        assert np.all(f[r::5] == f[r])
     assert e.heads(cands[:0], query)["overlap"].shape == (0,)
 
 
