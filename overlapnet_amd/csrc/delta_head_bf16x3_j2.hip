@@ -1,20 +1,8 @@
-// Delta head, DeltaLayer + c_conv1 + c_conv2 fused, on the bf16 matrix cores with a 3-term split
-// (v_mfma_f32_16x16x32_bf16, fp32 accumulate) for gfx950.
-//
-// Same math and same work decomposition as delta_head.hip (reference generateNet.py:15-61, :96-106); what
-// changes is the arithmetic of each product.  Every fp32 operand x is written as hi + lo with
-// hi = bf16(x), lo = bf16(x - hi), and a*w is evaluated as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo: three MFMAs at the
-// bf16 rate (16x the fp32 matrix rate) instead of one fp32 MFMA.  The dropped a_lo*w_lo term and the rounding of
-// lo are ~2^-17 relative per product; sums are fp32.  The overlap tolerance of the north star (1e-4 after the
-// sigmoid, i.e. ~4e-4 on the logit) is checked against the fp64 oracle in tests/test_gpu_parity.py for this mode.
-//
-// One workgroup (8 waves) = one pair, wave w owns rows 48w..48w+47 (3 MFMA row tiles) of the 360 x 64 c_conv1
-// output of each column group jb.  K = (c, dj) is walked channel-slice-major: an MFMA step covers 32 channels
-// (lane group g = lane>>4 takes channels 32g + 8s .. 32g + 8s + 7 for slice s = 0..3) of one R row dj, and the
-// 15 rows dj of a slice are consecutive steps -- so a lane needs only 8 floats of L per row tile at a time
-// (24 VGPRs instead of 96; the next slice is prefetched from L2 while the current one is consumed).
-// |L-R| is formed and split on the VALU while the matrix pipe works on the previous step.  W1 (hi and lo, pre-permuted to this order) streams through a double-buffered
-// 2 x 16 KB LDS window shared by the 8 waves; o1 goes to LDS as hi/lo bf16 in GEMM2's [24][960] A layout.
+// Delta head, bf16x3, TWO column groups per pass of the W1 stream (the default schedule; OVN_DELTA_SCHED=0/1 select the
+// one-group kernels of delta_head_bf16x3.hip).  Measured 5.76 ms vs 6.36 ms per 1024 pairs.
+// Same math, weight layouts and o1/GEMM2 machinery as delta_head_bf16x3.hip; the K walk of c_conv1 is shared by the column
+// groups jb and jb+1: every W1 fragment read from LDS, every staged W1 chunk, every barrier and every L slice load now
+// serves 24 instead of 12 MFMAs per row tile.  Costs: 2x accumulators (96 VGPRs at 3 row tiles per wave).
 #include <stdlib.h>
 
 #include "ovn_internal.h"
@@ -35,7 +23,7 @@ constexpr int STEPS_PER_CHUNK = 3;    // MFMA steps per W1 window chunk; 5 chunk
 constexpr int NCHUNK = 4 * S / STEPS_PER_CHUNK;   // 20 chunks per column group
 constexpr int STEP_BYTES = 8192;      // [nt(4)][hi/lo][lane(64)][8 bf16]
 constexpr int CHUNK_BYTES = STEPS_PER_CHUNK * STEP_BYTES;
-constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + (size_t)S * FC * 4 + 2 * CHUNK_BYTES;
+constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + 2 * (size_t)S * FC * 4 + 2 * CHUNK_BYTES;
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -71,46 +59,8 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(x - (float)hi);
 }
 
-// W1p[u = s*15 + dj][nt(4)][hl(2)][lane(64)][e(8)]: W1[dj][c = 32*(lane>>4) + 8*s + e][o = 16*nt + (lane&15)]
-__global__ void delta_prep_w1_bf16_kernel(const float* __restrict__ w1, __bf16* __restrict__ w1p) {
-  const int total = S * 4 * 4 * 64 * 8;  // (hi, lo) pairs
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int e = idx & 7;
-    const int lane = (idx >> 3) & 63;
-    const int nt = (idx >> 9) & 3;
-    const int u = idx >> 11;  // 0..59
-    const int s = u / S;
-    const int dj = u - s * S;
-    const int c = 32 * (lane >> 4) + 8 * s + e;
-    const int o = 16 * nt + (lane & 15);
-    __bf16 hi, lo;
-    split_bf16(w1[(dj * FC + c) * O1 + o], hi, lo);
-    const size_t base = (((size_t)u * 4 + nt) * 2) * 512 + lane * 8 + e;
-    w1p[base] = hi;
-    w1p[base + 512] = lo;
-  }
-}
-
-// W2p[ks(30)][nt(8)][hl(2)][lane(64)][e(8)]: W2[k = 32*ks + 8*(lane>>4) + e][p = 16*nt + (lane&15)], k = di*64 + o
-__global__ void delta_prep_w2_bf16_kernel(const float* __restrict__ w2, __bf16* __restrict__ w2p) {
-  const int total = (K2 / 32) * 8 * 64 * 8;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int e = idx & 7;
-    const int lane = (idx >> 3) & 63;
-    const int nt = (idx >> 9) & 7;
-    const int ks = idx >> 12;
-    const int k = 32 * ks + 8 * (lane >> 4) + e;
-    const int p = 16 * nt + (lane & 15);
-    __bf16 hi, lo;
-    split_bf16(w2[k * O2 + p], hi, lo);
-    const size_t base = (((size_t)ks * 8 + nt) * 2) * 512 + lane * 8 + e;
-    w2p[base] = hi;
-    w2p[base + 512] = lo;
-  }
-}
-
 template <int T, int NW>
-__global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* __restrict__ feats_l,
+__global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const float* __restrict__ feats_l,
                                                                const int32_t* __restrict__ lidx,
                                                                const float* __restrict__ feats_r,
                                                                const int32_t* __restrict__ ridx,
@@ -122,7 +72,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
   __bf16* o1h = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* o1l = o1h + G * O1_STRIDE;
   float* rs = reinterpret_cast<float*>(o1l + G * O1_STRIDE);
-  unsigned char* wst = reinterpret_cast<unsigned char*>(rs + S * FC);  // 2 x 16 KB
+  unsigned char* wst = reinterpret_cast<unsigned char*>(rs + 2 * S * FC);  // 2 x 24 KB window
 
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
@@ -144,7 +94,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
     const int i = 16 * T * wave + 16 * t + lrow;
     lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
   }
-  f32x4 la[T][2], lb[T][2];  // even / odd channel slices ping-pong (no register rotation)
+  f32x4 la[T][2];  // even / odd channel slices ping-pong (no register rotation)
 #define OVN_LOAD_L(DST, SL)                                                                              \
   _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
     if (lrow_off[t] >= 0) {                                                                              \
@@ -161,7 +111,6 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
   const int s0 = rot ? ((blockIdx.x >> 3) & 3) : 0;
   const int s1 = (s0 + 1) & 3, s2 = (s0 + 2) & 3, s3 = (s0 + 3) & 3;
   OVN_LOAD_L(la, s0)
-  OVN_LOAD_L(lb, s1)
 
   // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 20 chunks, so the window just wraps)
   const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
@@ -175,18 +124,16 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
   int chunk = 5 * s0;  // running chunk index 0..19 (cyclic), 5 chunks per slice
 
   // 12 MFMAs of one row tile; term-major so consecutive MFMAs never chain on one accumulator
-#define OVN_TILE_MFMA(T, AH, AL)                                                                          \
+#define OVN_TILE_MFMA(J, T, AH, AL)                                                                       \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
-      acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bh[nt], acc[T][nt], 0, 0, 0);              \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bh[nt], acc[J][T][nt], 0, 0, 0);        \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
-      acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, bh[nt], acc[T][nt], 0, 0, 0);              \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AL, bh[nt], acc[J][T][nt], 0, 0, 0);        \
   _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
-      acc[T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bl[nt], acc[T][nt], 0, 0, 0);
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AH, bl[nt], acc[J][T][nt], 0, 0, 0);
   // One channel slice SL (15 MFMA steps = 5 window chunks) with the L slice held in LX.
 #define OVN_SLICE(LX, SL)                                                                                         \
   {                                                                                                               \
-    f32x4 rp0 = *reinterpret_cast<const f32x4*>(rs + 32 * g + 8 * (SL));                                          \
-    f32x4 rp1 = *reinterpret_cast<const f32x4*>(rs + 32 * g + 8 * (SL) + 4);                                      \
     for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
       const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
       const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
@@ -196,11 +143,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
         const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
         const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
         const float* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                     \
-        const f32x4 r0 = rp0, r1 = rp1; /* fetched one step ahead */                                              \
-        if (dj + 1 < S) {                                                                                         \
-          rp0 = *reinterpret_cast<const f32x4*>(rrow + FC);                                                       \
-          rp1 = *reinterpret_cast<const f32x4*>(rrow + FC + 4);                                                   \
-        }                                                                                                         \
+        const f32x4 ra0 = *reinterpret_cast<const f32x4*>(rrow);                                                  \
+        const f32x4 ra1 = *reinterpret_cast<const f32x4*>(rrow + 4);                                              \
+        const f32x4 rb0 = *reinterpret_cast<const f32x4*>(rrow + S * FC);                                         \
+        const f32x4 rb1 = *reinterpret_cast<const f32x4*>(rrow + S * FC + 4);                                     \
         bf16x8 bh[4], bl[4];                                                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
           bh[nt] = *reinterpret_cast<const bf16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                      \
@@ -208,8 +154,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
         }                                                                                                         \
         _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                           \
           bf16x8 ah, al;                                                                                          \
-          make_a(LX[t][0], LX[t][1], r0, r1, ah, al);                                                             \
-          OVN_TILE_MFMA(t, ah, al)                                                                                \
+          make_a(LX[t][0], LX[t][1], ra0, ra1, ah, al);                                                           \
+          OVN_TILE_MFMA(0, t, ah, al)                                                                             \
+          make_a(LX[t][0], LX[t][1], rb0, rb1, ah, al);                                                           \
+          OVN_TILE_MFMA(1, t, ah, al)                                                                             \
         }                                                                                                         \
       }                                                                                                           \
       unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                        \
@@ -221,28 +169,34 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
     }                                                                                                             \
   }
 
-  for (int jb = 0; jb < G; ++jb) {
-    __syncthreads();  // previous group's GEMM2 is done with o1h/o1l and rs; W window write above is visible
-    if (tid < S * FC / 4)
-      *reinterpret_cast<f32x4*>(rs + 4 * tid) = *reinterpret_cast<const f32x4*>(R + jb * S * FC + 4 * tid);
+  for (int jb2 = 0; jb2 < G / 2; ++jb2) {
+    __syncthreads();  // previous pass's GEMM2 is done with o1h/o1l and rs; W window write above is visible
+    for (int i4 = tid; i4 < 2 * S * FC / 4; i4 += NT_)
+      *reinterpret_cast<f32x4*>(rs + 4 * i4) = *reinterpret_cast<const f32x4*>(R + jb2 * 2 * S * FC + 4 * i4);
     __syncthreads();
 
-    f32x4 acc[T][4];
+    f32x4 acc[2][T][4];
 #pragma unroll
-    for (int t = 0; t < T; ++t)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    // slices 0..3; an L register set is refilled (from L2) as soon as its slice is consumed, 15 steps ahead of use
+    // single L register set (the second accumulator set took the ping-pong's registers): each slice load is exposed
     OVN_SLICE(la, s0)
+    OVN_LOAD_L(la, s1)
+    OVN_SLICE(la, s1)
     OVN_LOAD_L(la, s2)
-    OVN_SLICE(lb, s1)
-    OVN_LOAD_L(lb, s3)
     OVN_SLICE(la, s2)
+    OVN_LOAD_L(la, s3)
+    OVN_SLICE(la, s3)
     OVN_LOAD_L(la, s0)
-    OVN_SLICE(lb, s3)
-    OVN_LOAD_L(lb, s1)
 
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+    const int jb = 2 * jb2 + j;
+    if (j == 1) __syncthreads();  // GEMM2 of the first group is done with the o1 image
     // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -257,7 +211,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
             const int ib = i / S;
             const int di = i - ib * S;
             __bf16 h, l;
-            split_bf16(acc[t][nt][r] + bv, h, l);
+            split_bf16(acc[j][t][nt][r] + bv, h, l);
             o1h[ib * O1_STRIDE + di * O1 + o] = h;
             o1l[ib * O1_STRIDE + di * O1 + o] = l;
           }
@@ -309,6 +263,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
         }
       }
     }
+    }
   }
 }
 
@@ -317,51 +272,17 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_kernel(const float* 
 #undef OVN_TILE_MFMA
 }  // namespace
 
-int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_dev, void** w1p_out, void** w2p_out,
-                             hipStream_t stream) {
-  const size_t w1_elems = (size_t)S * FC * O1 * 2;   // hi + lo
-  const size_t w2_elems = (size_t)K2 * O2 * 2;
-  OVN_HIP_CHECK(hipMalloc(w1p_out, w1_elems * sizeof(__bf16)));
-  OVN_HIP_CHECK(hipMalloc(w2p_out, w2_elems * sizeof(__bf16)));
-  hipLaunchKernelGGL(delta_prep_w1_bf16_kernel, dim3(240), dim3(256), 0, stream, c1_kernel_dev,
-                     reinterpret_cast<__bf16*>(*w1p_out));
-  hipLaunchKernelGGL(delta_prep_w2_bf16_kernel, dim3(240), dim3(256), 0, stream, c2_kernel_dev,
-                     reinterpret_cast<__bf16*>(*w2p_out));
-  OVN_HIP_CHECK(hipGetLastError());
-  return OVN_OK;
-}
-
-int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                 const int32_t* ridx, int n, float* o2, hipStream_t stream) {
-  static int rot = -1;
-  if (rot < 0) {
-    const char* e = getenv("OVN_DELTA_ROT");
-    rot = e ? atoi(e) : 1;
-  }
-  // schedule: 2 (default) = two column groups per W1 pass, 8 waves x 3 row tiles (delta_head_bf16x3_j2.hip);
-  //           0 = one column group per pass, 8 waves x 3 row tiles; 1 = one group, 12 waves x 2 row tiles
-  static int sched = -1;
-  if (sched < 0) {
-    const char* e = getenv("OVN_DELTA_SCHED");
-    sched = e ? atoi(e) : 2;
-  }
+int ovn_delta_c12_bf16x3_j2_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                    const int32_t* ridx, int n, float* o2, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel<3, 8>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_kernel<2, 12>),
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
-  if (sched == 2) return ovn_delta_c12_bf16x3_j2_forward(ctx, feats_l, lidx, feats_r, ridx, n, o2, stream);
-  if (sched == 1)
-    hipLaunchKernelGGL((delta_c12_bf16x3_kernel<2, 12>), dim3(n), dim3(768), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
-                       reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
-                       ctx->c2.bias, o2, rot);
-  else
-    hipLaunchKernelGGL((delta_c12_bf16x3_kernel<3, 8>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
-                       reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
-                       ctx->c2.bias, o2, rot);
+  hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
+                     reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
+                     ctx->c2.bias, o2, 1);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
