@@ -59,7 +59,7 @@ __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   lo = (__bf16)(x - (float)hi);
 }
 
-template <int T, int NW>
+template <int T, int NW, bool DMA>
 __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const float* __restrict__ feats_l,
                                                                const int32_t* __restrict__ lidx,
                                                                const float* __restrict__ feats_r,
@@ -137,8 +137,14 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
       const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
       const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
-      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
-          pf[q] = *reinterpret_cast<const f32x4*>(src + (q * NT_ + tid) * 16);                                    \
+      if (DMA) {                                                                                                  \
+        _Pragma("unroll") for (int q = 0; q < PFN; ++q) __builtin_amdgcn_global_load_lds(                         \
+            (const __attribute__((address_space(1))) void*)(src + (q * NT_ + tid) * 16),                         \
+            (__attribute__((address_space(3))) void*)(wst + (cur ^ 1) * CHUNK_BYTES + (q * NT_ + (tid & ~63)) * 16), 16, 0, 0); \
+      } else {                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                           \
+            pf[q] = *reinterpret_cast<const f32x4*>(src + (q * NT_ + tid) * 16);                                  \
+      }                                                                                                           \
       _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
         const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
         const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
@@ -160,9 +166,11 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
           OVN_TILE_MFMA(1, t, ah, al)                                                                             \
         }                                                                                                         \
       }                                                                                                           \
-      unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                        \
-      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
-          *reinterpret_cast<f32x4*>(dstw + (q * NT_ + tid) * 16) = pf[q];                                         \
+      if (!DMA) {                                                                                                 \
+        unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                      \
+        _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                           \
+            *reinterpret_cast<f32x4*>(dstw + (q * NT_ + tid) * 16) = pf[q];                                       \
+      }                                                                                                           \
       __syncthreads();                                                                                            \
       cur ^= 1;                                                                                                   \
       chunk = nxt;                                                                                                \
@@ -274,15 +282,27 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
 
 int ovn_delta_c12_bf16x3_j2_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                     const int32_t* ridx, int n, float* o2, hipStream_t stream) {
+  static int dma = -1;
+  if (dma < 0) {
+    const char* e = getenv("OVN_DELTA_DMA");
+    dma = e ? atoi(e) : 0;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8>),
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
     attr_set = true;
   }
-  hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r, ridx,
-                     reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
-                     ctx->c2.bias, o2, 1);
+  if (dma)
+    hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8, true>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r,
+                       ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1,
+                       reinterpret_cast<const __bf16*>(ctx->w2p_bf), ctx->c2.bias, o2, 1);
+  else
+    hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8, false>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r,
+                       ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1,
+                       reinterpret_cast<const __bf16*>(ctx->w2p_bf), ctx->c2.bias, o2, 1);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
