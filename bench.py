@@ -39,20 +39,21 @@ PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_16
 PEAK_BF16_MFMA_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse figure)
 
 
-def rocprof_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary under profiles/
-    (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md; see
-    tools/summarize_rocprof.py) -- null if no summary names the kernel.  Counters cannot be read live in-process."""
+def rocprof_traffic(kernel_prefix: str):
+    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the NEWEST committed rocprofv3
+    PMC summary under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md;
+    see tools/summarize_rocprof.py) -- null if no summary names it.  Counters cannot be read live in-process."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json"))):
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")), key=os.path.getmtime)
+    for f in reversed(files):
         try:
             t = json.load(open(f)).get("hbm_traffic_per_launch", {})
         except Exception:
             continue
-        if kernel in t:
-            best = t[kernel]["total_bytes"]
-    return best
+        hits = [v["total_bytes"] for k, v in t.items() if k.startswith(kernel_prefix)]
+        if hits:
+            return max(hits)
+    return None
 
 
 def cpu_baseline(channels: int, pool: int):
@@ -237,7 +238,7 @@ def main():
             peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, "delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)", "f32"
             rl_note = "fp32 matrix cores, one MFMA per product"
         else:
-            peak, kname, dtype = PEAK_BF16_MFMA_TFLOPS, "delta_c12_bf16x3_kernel (DeltaLayer+c_conv1+c_conv2, bf16 MFMA)", "bf16x3"
+            peak, kname, dtype = PEAK_BF16_MFMA_TFLOPS, "delta_c12_bf16x3_j2_kernel (DeltaLayer+c_conv1+c_conv2, bf16 MFMA)", "bf16x3"
             rl_note = ("achieved counts ALGORITHMIC flops; the 3-term bf16 split issues 3 MFMA flops per algorithmic "
                        "flop, so the matrix pipe executes 3x this rate (frac <= 1/3 by construction)")
         kernels = {k: {"ms_per_launch": (v[0] / v[1] if v[1] else None), "launches": v[1]} for k, v in prof.items() if v[1]}
@@ -256,7 +257,7 @@ def main():
                        "correlation_head": args.corr,
                        "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
             "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": rocprof_traffic(kname.split(" ")[0]),
+                         "frac": achieved / peak, "traffic": rocprof_traffic("delta_c12_bf16x3" if dtype == "bf16x3" else "delta_c12_kernel"),
                          "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * P, "avg_launch_ms": avg_ms, "note": rl_note},
             "kernels": kernels,
             "head_hbm_gbps_algorithmic": (P * world * args.steps / elapsed) * CAND_BYTES_PER_PAIR / 1e9,

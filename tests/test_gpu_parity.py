@@ -418,3 +418,77 @@ def test_spectral_correlation_head(engines):
     a = e.corr_head_spectral(spec, spec[2:3].contiguous())
     b = e.corr_head_spectral(spec, spec, lidx=np.arange(7), ridx=np.full(7, 2))
     assert torch.equal(a["yaw"], b["yaw"])
+
+
+def test_infer_with_intensity_channel_and_missing_files(tmp_path, fixture_npz):
+    """C = 5 (depth + normals + intensity, ImagePairOverlapOrientationSequence.py:143-207 channel order) through `Infer`,
+    and the reference's error behaviour for unreadable inputs (:148-149,159-160)."""
+    from overlapnet_amd.infer import Infer
+    seq = tmp_path / "data" / "s"
+    for sub in ("depth", "normal", "intensity"):
+        os.makedirs(seq / sub)
+    imgs = []
+    for i in range(2):
+        np.save(seq / "depth" / ("%06d.npy" % i), fixture_npz["range_%d" % i])
+        np.save(seq / "normal" / ("%06d.npy" % i), fixture_npz["normal_%d" % i])
+        np.save(seq / "intensity" / ("%06d.npy" % i), fixture_npz["intensity_%d" % i])
+        imgs.append(S.stack(fixture_npz["range_%d" % i], fixture_npz["normal_%d" % i], fixture_npz["intensity_%d" % i],
+                            (True, True, True)))
+    cfg = {"model": dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900]), "infer_seqs": "s",
+           "data_root_folder": str(tmp_path / "data"), "use_depth": True, "use_normals": True,
+           "use_class_probabilities": False, "use_class_probabilities_pca": False, "use_intensity": True,
+           "batch_size": 1, "pretrained_weightsfilename": ""}
+    w = S.make_test_weights(5, seed=0)
+    inf = Infer(cfg, weights=w)
+    assert inf.no_input_channels == 5 and cfg["model"]["inputShape"] == [64, 900, 5]
+    fv = inf.create_feature_volumes(["000000", "000001"])       # batch_size 1 -> two leg launches
+    ref = O.leg_forward(np.stack(imgs), w, CFG, np.float64)
+    assert _rel(fv, ref) < 2e-5
+    ov, yaw = inf.infer_one("a/000000.bin", "b/000001.bin")
+    o_ov, o_yaw, _, _ = O.heads_forward(ref[[1]], ref[[0]], w)
+    assert abs(ov[0] - o_ov[0]) < 1e-4 and yaw[0] == o_yaw[0]
+    with pytest.raises(Exception, match="Could not read depth image"):
+        inf.create_feature_volumes(["000007"])
+    os.remove(seq / "normal" / "000001.npy")
+    with pytest.raises(Exception, match="Could not read normal image"):
+        inf.create_feature_volumes(["000001"])
+    cfg2 = dict(cfg, infer_seqs="nowhere", model=dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900]))
+    with pytest.raises(Exception, match="first generate preprocessed"):
+        Infer(cfg2, weights=w).infer_one("x/000000.bin", "y/000001.bin")
+    # a KeyError for a missing use_* key, exactly like infer.py:62-73
+    cfg3 = {k: v for k, v in cfg.items() if k != "use_intensity"}
+    cfg3["model"] = dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900])
+    with pytest.raises(KeyError):
+        Infer(cfg3, weights=w)
+
+
+def test_full_size_sweep_properties(engines):
+    """BASELINE-sized 1-vs-1024 sweep, size-independent properties: candidate k = query rolled by k columns must
+    come back with yaw bin 180 + k (mod 360) -> yaw = -k wrapped, and rolling leaves the overlap logit of the
+    SELF pair's neighbourhood finite and deterministic; both correlation forms agree; both heads agree with the
+    small-batch call on the same pairs (chunking / batching invariance of the spectral + Delta path)."""
+    rng = np.random.default_rng(77)
+    q = np.maximum(rng.normal(0.2, 1.0, size=(360, 128)), 0).astype(np.float32)
+    shifts = (np.arange(1024) * 7) % 360
+    cands = np.stack([np.roll(q, int(s), axis=0) for s in shifts])
+    e = engines[4]
+    ct = torch.from_numpy(cands).cuda()
+    qt = torch.from_numpy(q[None]).cuda()
+    spec, qspec = e.spectrum(ct), e.spectrum(qt)
+    r = e.heads(ct, qt, spec_l=spec, spec_r=qspec, want_logit=True)
+    yaw = r["yaw"].cpu().numpy()
+    expect = 180 - ((180 + shifts) % 360)
+    assert np.array_equal(yaw, expect)
+    d = e.heads(ct, qt, want_logit=True)                      # direct correlation form
+    assert np.array_equal(d["yaw"].cpu().numpy(), expect)
+    lg = r["logit"].cpu().numpy()
+    assert np.all(np.isfinite(lg))
+    # same pairs in a small batch: same values up to the bf16x3 position jitter
+    small = e.heads(ct[100:116].contiguous(), qt, want_logit=True)["logit"].cpu().numpy()
+    assert np.all(np.abs(small - lg[100:116]) <= 2e-5 * (1 + np.abs(small)))
+    # shift 0 is the self pair: identical features -> |L-R| contains the zero diagonal; oracle check on 3 pairs
+    idx = np.array([0, 1, 513])
+    o_ov, o_yaw, _, _ = O.heads_forward(cands[idx].reshape(3, 1, 360, 128).astype(np.float64),
+                                        np.repeat(q.reshape(1, 1, 360, 128).astype(np.float64), 3, axis=0),
+                                        S.make_test_weights(4, seed=0))
+    assert np.max(np.abs(r["overlap"].cpu().numpy()[idx] - o_ov)) <= 1e-4 and np.array_equal(yaw[idx], o_yaw)
