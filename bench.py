@@ -44,7 +44,7 @@ def rocprof_traffic(kernel_prefix: str):
     PMC summary under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md;
     see tools/summarize_rocprof.py) -- null if no summary names it.  Counters cannot be read live in-process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")), key=os.path.getmtime)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")))  # r1 < r1b < ... by name
     for f in reversed(files):
         try:
             t = json.load(open(f)).get("hbm_traffic_per_launch", {})
