@@ -1,0 +1,702 @@
+"""Minimal read-only HDF5 parser, enough for Keras weight files, with no dependency beyond NumPy.
+
+Why it exists: the reference loads its trained network from a Keras HDF5 file
+(`src/two_heads/infer.py:117-120`, written by `model.save`, `src/two_heads/training.py:349`) and h5py is not
+part of the ROCm image this framework targets.  The file layout Keras 2.1.x produces through h5py's defaults
+(libver 'earliest') is: superblock v0, old-style groups (symbol-table message -> B-tree v1 + local heap +
+SNOD nodes), version-1 object headers, contiguous little-endian float32 datasets and fixed-length string
+attributes (`layer_names`, `weight_names`).  All of that is handled, plus what files re-saved by newer
+stacks tend to contain: superblock v2/v3, version-2 object headers with compact link messages, compact and
+chunked layouts (B-tree v1 chunk index; deflate / shuffle / fletcher32 filters), variable-length string
+attributes (global heap).  Anything else (dense link storage, virtual / external datasets, layout v4
+chunk indices, compound types) raises `Hdf5Error` naming the feature -- never a silent wrong read.
+
+The object model follows h5py's names where it has them (`File`, `Group.keys/items/attrs/visititems`,
+`Dataset.shape/dtype/[()]`) so that `weights.load_keras_hdf5` reads the same with either.
+
+Format reference: the public "HDF5 File Format Specification Version 2.0 / 3.0" (field order restated from it).
+"""
+from __future__ import annotations
+
+import struct
+import zlib
+from typing import Callable, Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+SIGNATURE = b"\x89HDF\r\n\x1a\n"
+UNDEF = 0xFFFFFFFFFFFFFFFF
+
+
+class Hdf5Error(Exception):
+    pass
+
+
+def _pad8(n: int) -> int:
+    return (n + 7) & ~7
+
+
+class _Reader:
+    """Random-access little-endian reader over the whole file image."""
+
+    def __init__(self, buf: bytes):
+        self.buf = buf
+        self.O = 8  # size of offsets, set from the superblock
+        self.L = 8  # size of lengths
+        self.base = 0
+
+    def u(self, pos: int, size: int) -> int:
+        if pos < 0 or pos + size > len(self.buf):
+            raise Hdf5Error("read of %d bytes at %d is outside the file (%d bytes): truncated file?"
+                            % (size, pos, len(self.buf)))
+        return int.from_bytes(self.buf[pos:pos + size], "little")
+
+    def bytes(self, pos: int, size: int) -> bytes:
+        if pos < 0 or pos + size > len(self.buf):
+            raise Hdf5Error("read of %d bytes at %d is outside the file (%d bytes): truncated file?"
+                            % (size, pos, len(self.buf)))
+        return self.buf[pos:pos + size]
+
+    def off(self, pos: int) -> int:
+        v = self.u(pos, self.O)
+        return UNDEF if v == (1 << (8 * self.O)) - 1 else v
+
+    def len_(self, pos: int) -> int:
+        return self.u(pos, self.L)
+
+    def addr(self, a: int) -> int:
+        return a + self.base
+
+
+# ----------------------------------------------------------------------------------------------------------
+# datatypes
+# ----------------------------------------------------------------------------------------------------------
+class _Dtype:
+    """Parsed datatype message: either a NumPy dtype or a variable-length string marker."""
+
+    def __init__(self, np_dtype: Optional[np.dtype], size: int, vlen_str: bool = False, is_str: bool = False,
+                 strpad: int = 0):
+        self.np_dtype = np_dtype
+        self.size = size
+        self.vlen_str = vlen_str
+        self.is_str = is_str
+        self.strpad = strpad
+
+
+def _parse_datatype(r: _Reader, pos: int) -> _Dtype:
+    cv = r.u(pos, 1)
+    cls, ver = cv & 0x0F, cv >> 4
+    bits = r.u(pos + 1, 3)
+    size = r.u(pos + 4, 4)
+    if ver not in (1, 2, 3):
+        raise Hdf5Error("datatype message version %d not supported" % ver)
+    if cls == 0:  # fixed point
+        order = ">" if bits & 1 else "<"
+        signed = bool(bits & 0x08)
+        if size not in (1, 2, 4, 8):
+            raise Hdf5Error("integer datatype of %d bytes not supported" % size)
+        return _Dtype(np.dtype("%s%s%d" % (order, "i" if signed else "u", size)), size)
+    if cls == 1:  # floating point
+        if bits & 0x40:
+            raise Hdf5Error("VAX-endian floating point not supported")
+        order = ">" if bits & 1 else "<"
+        if size not in (2, 4, 8):
+            raise Hdf5Error("floating-point datatype of %d bytes not supported" % size)
+        return _Dtype(np.dtype("%sf%d" % (order, size)), size)
+    if cls == 3:  # fixed-length string
+        return _Dtype(np.dtype("S%d" % size), size, is_str=True, strpad=bits & 0x0F)
+    if cls == 9:  # variable length
+        vtype = bits & 0x0F
+        if vtype != 1:
+            raise Hdf5Error("variable-length sequences (non-string) not supported")
+        return _Dtype(None, size, vlen_str=True, is_str=True)
+    names = {2: "time", 4: "bitfield", 5: "opaque", 6: "compound", 7: "reference", 8: "enum", 10: "array"}
+    raise Hdf5Error("datatype class %d (%s) not supported" % (cls, names.get(cls, "?")))
+
+
+def _parse_dataspace(r: _Reader, pos: int) -> Optional[Tuple[int, ...]]:
+    """Returns the shape; () for scalar; None for the null dataspace."""
+    ver = r.u(pos, 1)
+    rank = r.u(pos + 1, 1)
+    flags = r.u(pos + 2, 1)
+    if ver == 1:
+        p = pos + 8
+    elif ver == 2:
+        if r.u(pos + 3, 1) == 2:
+            return None
+        p = pos + 4
+    else:
+        raise Hdf5Error("dataspace message version %d not supported" % ver)
+    return tuple(r.len_(p + i * r.L) for i in range(rank))
+
+
+# ----------------------------------------------------------------------------------------------------------
+# object headers
+# ----------------------------------------------------------------------------------------------------------
+MSG_DATASPACE, MSG_LINKINFO, MSG_DATATYPE, MSG_LINK, MSG_LAYOUT = 0x01, 0x02, 0x03, 0x06, 0x08
+MSG_FILTERS, MSG_ATTRIBUTE, MSG_CONTINUATION, MSG_SYMTAB = 0x0B, 0x0C, 0x10, 0x11
+MSG_SHARED_FLAG = 0x02
+
+
+def _messages(r: _Reader, addr: int) -> List[Tuple[int, int, int, int]]:
+    """All messages of the object header at `addr` as (type, flags, data position, data size)."""
+    pos = r.addr(addr)
+    out: List[Tuple[int, int, int, int]] = []
+    if r.bytes(pos, 4) == b"OHDR":
+        ver = r.u(pos + 4, 1)
+        if ver != 2:
+            raise Hdf5Error("object header version %d not supported" % ver)
+        flags = r.u(pos + 5, 1)
+        p = pos + 6
+        if flags & 0x20:
+            p += 16
+        if flags & 0x10:
+            p += 4
+        csz = 1 << (flags & 3)
+        chunk0 = r.u(p, csz)
+        p += csz
+        track_order = bool(flags & 0x04)
+        blocks = [(p, chunk0)]
+        while blocks:
+            start, size = blocks.pop(0)
+            q, end = start, start + size
+            while q + 4 <= end:
+                mtype = r.u(q, 1)
+                msize = r.u(q + 1, 2)
+                mflags = r.u(q + 3, 1)
+                q += 4 + (2 if track_order else 0)
+                if q + msize > end:
+                    break  # gap before the checksum
+                if mtype == MSG_CONTINUATION:
+                    coff, clen = r.off(q), r.len_(q + r.O)
+                    cpos = r.addr(coff)
+                    if r.bytes(cpos, 4) != b"OCHK":
+                        raise Hdf5Error("object header continuation at %d lacks the OCHK signature" % coff)
+                    blocks.append((cpos + 4, clen - 8))  # signature in front, checksum behind
+                elif mtype != 0:
+                    out.append((mtype, mflags, q, msize))
+                q += msize
+        return out
+    ver = r.u(pos, 1)
+    if ver != 1:
+        raise Hdf5Error("no object header at address %d (version byte %d)" % (addr, ver))
+    nmsg = r.u(pos + 2, 2)
+    hsize = r.u(pos + 8, 4)
+    blocks = [(pos + 16, hsize)]
+    seen = 0
+    while blocks and seen < nmsg:
+        start, size = blocks.pop(0)
+        q, end = start, start + size
+        while q + 8 <= end and seen < nmsg:
+            mtype = r.u(q, 2)
+            msize = r.u(q + 2, 2)
+            mflags = r.u(q + 4, 1)
+            q += 8
+            seen += 1
+            if mtype == MSG_CONTINUATION:
+                blocks.append((r.addr(r.off(q)), r.len_(q + r.O)))
+            elif mtype != 0:
+                out.append((mtype, mflags, q, msize))
+            q += msize
+    return out
+
+
+def _read_vlen_strings(r: _Reader, raw: bytes, count: int) -> List[bytes]:
+    out = []
+    step = 4 + r.O + 4
+    for i in range(count):
+        ln = int.from_bytes(raw[i * step:i * step + 4], "little")
+        coll = int.from_bytes(raw[i * step + 4:i * step + 4 + r.O], "little")
+        idx = int.from_bytes(raw[i * step + 4 + r.O:i * step + step], "little")
+        if coll == 0 or ln == 0:
+            out.append(b"")
+            continue
+        out.append(_global_heap_object(r, coll, idx)[:ln])
+    return out
+
+
+def _global_heap_object(r: _Reader, coll_addr: int, index: int) -> bytes:
+    pos = r.addr(coll_addr)
+    if r.bytes(pos, 4) != b"GCOL":
+        raise Hdf5Error("global heap collection signature missing at %d" % coll_addr)
+    csize = r.len_(pos + 8)
+    q, end = pos + 8 + r.L, pos + csize
+    while q + 8 + r.L <= end:
+        idx = r.u(q, 2)
+        osize = r.len_(q + 8)
+        if idx == 0:
+            break
+        if idx == index:
+            return r.bytes(q + 8 + r.L, osize)
+        q += 8 + r.L + _pad8(osize)
+    raise Hdf5Error("global heap object %d not found in the collection at %d" % (index, coll_addr))
+
+
+def _decode_values(r: _Reader, dt: _Dtype, shape: Optional[Tuple[int, ...]], raw: bytes):
+    if shape is None:
+        return None
+    count = int(np.prod(shape)) if shape else 1
+    if dt.vlen_str:
+        vals = _read_vlen_strings(r, raw, count)
+        arr = np.empty(count, dtype=object)
+        arr[:] = vals
+        return arr.reshape(shape) if shape else vals[0]
+    arr = np.frombuffer(raw, dtype=dt.np_dtype, count=count)
+    if dt.is_str:
+        # null-terminated / null-padded: NumPy's S dtype already strips trailing NULs; space-padded: strip spaces
+        if dt.strpad == 2:
+            arr = np.char.rstrip(arr, b" ")
+        return arr.reshape(shape).copy() if shape else bytes(arr[0])
+    arr = arr.astype(dt.np_dtype.newbyteorder("="), copy=True)
+    return arr.reshape(shape) if shape else arr[0]
+
+
+def _parse_attribute(r: _Reader, pos: int, mflags: int) -> Tuple[str, object]:
+    if mflags & MSG_SHARED_FLAG:
+        raise Hdf5Error("shared attribute messages not supported")
+    ver = r.u(pos, 1)
+    aflags = r.u(pos + 1, 1)
+    nsz, dsz, ssz = r.u(pos + 2, 2), r.u(pos + 4, 2), r.u(pos + 6, 2)
+    if ver == 1:
+        p = pos + 8
+        name = r.bytes(p, nsz)
+        p += _pad8(nsz)
+        dpos = p
+        p += _pad8(dsz)
+        spos = p
+        p += _pad8(ssz)
+    elif ver in (2, 3):
+        if aflags & 0x03:
+            raise Hdf5Error("attributes with shared datatype/dataspace not supported")
+        p = pos + 8 + (1 if ver == 3 else 0)
+        name = r.bytes(p, nsz)
+        p += nsz
+        dpos = p
+        p += dsz
+        spos = p
+        p += ssz
+    else:
+        raise Hdf5Error("attribute message version %d not supported" % ver)
+    dt = _parse_datatype(r, dpos)
+    shape = _parse_dataspace(r, spos)
+    count = 0 if shape is None else (int(np.prod(shape)) if shape else 1)
+    raw = r.bytes(p, count * dt.size)
+    return name.split(b"\x00")[0].decode("utf8"), _decode_values(r, dt, shape, raw)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# groups
+# ----------------------------------------------------------------------------------------------------------
+def _local_heap_data(r: _Reader, addr: int) -> Tuple[int, int]:
+    pos = r.addr(addr)
+    if r.bytes(pos, 4) != b"HEAP":
+        raise Hdf5Error("local heap signature missing at %d" % addr)
+    size = r.len_(pos + 8)
+    data = r.off(pos + 8 + 2 * r.L)
+    return r.addr(data), size
+
+
+def _cstring(r: _Reader, pos: int, limit: int) -> str:
+    end = r.buf.find(b"\x00", pos, pos + limit)
+    if end < 0:
+        raise Hdf5Error("unterminated link name in a local heap")
+    return r.buf[pos:end].decode("utf8")
+
+
+def _symtab_links(r: _Reader, btree_addr: int, heap_addr: int) -> Dict[str, int]:
+    heap_pos, heap_size = _local_heap_data(r, heap_addr)
+    links: Dict[str, int] = {}
+
+    def walk(addr: int) -> None:
+        pos = r.addr(addr)
+        sig = r.bytes(pos, 4)
+        if sig == b"TREE":
+            if r.u(pos + 4, 1) != 0:
+                raise Hdf5Error("group B-tree node has type %d" % r.u(pos + 4, 1))
+            n = r.u(pos + 6, 2)
+            p = pos + 8 + 2 * r.O
+            for i in range(n):
+                p += r.L  # key i
+                walk(r.off(p))
+                p += r.O
+        elif sig == b"SNOD":
+            n = r.u(pos + 6, 2)
+            p = pos + 8
+            esz = 2 * r.O + 24
+            for i in range(n):
+                noff = r.off(p)
+                ohdr = r.off(p + r.O)
+                ctype = r.u(p + 2 * r.O, 4)
+                if ctype == 2:
+                    raise Hdf5Error("symbolic links are not supported")
+                links[_cstring(r, heap_pos + noff, heap_size - noff)] = ohdr
+                p += esz
+        else:
+            raise Hdf5Error("unexpected signature %r in a group B-tree at %d" % (sig, addr))
+
+    walk(btree_addr)
+    return links
+
+
+def _parse_link_message(r: _Reader, pos: int) -> Tuple[str, int]:
+    ver = r.u(pos, 1)
+    if ver != 1:
+        raise Hdf5Error("link message version %d not supported" % ver)
+    flags = r.u(pos + 1, 1)
+    p = pos + 2
+    ltype = 0
+    if flags & 0x08:
+        ltype = r.u(p, 1)
+        p += 1
+    if flags & 0x04:
+        p += 8
+    if flags & 0x10:
+        p += 1
+    lsz = 1 << (flags & 3)
+    nlen = r.u(p, lsz)
+    p += lsz
+    name = r.bytes(p, nlen).decode("utf8")
+    p += nlen
+    if ltype != 0:
+        raise Hdf5Error("soft / external link '%s' not supported" % name)
+    return name, r.off(p)
+
+
+class _Node:
+    def __init__(self, file: "File", addr: int, name: str):
+        self._file = file
+        self._addr = addr
+        self.name = name
+        self._msgs = _messages(file._r, addr)
+        self._attrs: Optional[Dict[str, object]] = None
+
+    @property
+    def attrs(self) -> Dict[str, object]:
+        if self._attrs is None:
+            a: Dict[str, object] = {}
+            for mtype, mflags, pos, size in self._msgs:
+                if mtype == MSG_ATTRIBUTE:
+                    k, v = _parse_attribute(self._file._r, pos, mflags)
+                    a[k] = v
+                elif mtype == 0x15:  # attribute info: dense storage when a fractal heap address is set
+                    r = self._file._r
+                    flags = r.u(pos + 1, 1)
+                    p = pos + 2 + (2 if flags & 1 else 0)
+                    if r.off(p) != UNDEF:
+                        raise Hdf5Error("dense attribute storage (fractal heap) on '%s' is not supported; "
+                                        "re-save the file with libver='earliest'" % self.name)
+            self._attrs = a
+        return self._attrs
+
+
+class Dataset(_Node):
+    def __init__(self, file: "File", addr: int, name: str):
+        super().__init__(file, addr, name)
+        r = file._r
+        self._dt: Optional[_Dtype] = None
+        self.shape: Optional[Tuple[int, ...]] = None
+        self._layout: Optional[Tuple[int, int]] = None
+        self._filters: List[Tuple[int, List[int]]] = []
+        for mtype, mflags, pos, size in self._msgs:
+            if mflags & MSG_SHARED_FLAG and mtype in (MSG_DATATYPE, MSG_DATASPACE, MSG_FILTERS):
+                raise Hdf5Error("shared (committed) header messages on '%s' not supported" % name)
+            if mtype == MSG_DATATYPE:
+                self._dt = _parse_datatype(r, pos)
+            elif mtype == MSG_DATASPACE:
+                self.shape = _parse_dataspace(r, pos)
+            elif mtype == MSG_LAYOUT:
+                self._layout = (pos, size)
+            elif mtype == MSG_FILTERS:
+                self._filters = _parse_filters(r, pos)
+        if self._dt is None or self._layout is None:
+            raise Hdf5Error("'%s' is not a dataset (datatype/layout message missing)" % name)
+
+    @property
+    def dtype(self) -> np.dtype:
+        if self._dt.vlen_str:
+            return np.dtype(object)
+        return self._dt.np_dtype.newbyteorder("=") if not self._dt.is_str else self._dt.np_dtype
+
+    def read(self) -> np.ndarray:
+        r = self._file._r
+        dt, shape = self._dt, self.shape
+        if shape is None:
+            raise Hdf5Error("'%s' has a null dataspace" % self.name)
+        count = int(np.prod(shape)) if shape else 1
+        nbytes = count * dt.size
+        pos, _ = self._layout
+        ver = r.u(pos, 1)
+        if ver in (1, 2):
+            rank = r.u(pos + 1, 1)
+            cls = r.u(pos + 2, 1)
+            p = pos + 8
+            addr = UNDEF
+            if cls != 0:
+                addr = r.off(p)
+                p += r.O
+            dims = [r.u(p + 4 * i, 4) for i in range(rank)]
+            p += 4 * rank
+            if cls == 0:
+                csize = r.u(p, 4)
+                raw = r.bytes(p + 4, csize)
+            elif cls == 1:
+                raw = self._contiguous(addr, nbytes)
+            else:
+                raw = self._chunked(addr, rank, dims, nbytes)
+        elif ver in (3, 4):  # v4 (libver='latest') keeps the v3 fields for compact / contiguous storage
+            cls = r.u(pos + 1, 1)
+            if cls == 0:
+                csize = r.u(pos + 2, 2)
+                raw = r.bytes(pos + 4, csize)
+            elif cls == 1:
+                raw = self._contiguous(r.off(pos + 2), nbytes)
+            elif cls == 2 and ver == 3:
+                rank = r.u(pos + 2, 1)
+                addr = r.off(pos + 3)
+                dims = [r.u(pos + 3 + r.O + 4 * i, 4) for i in range(rank)]
+                raw = self._chunked(addr, rank, dims, nbytes)
+            else:
+                raise Hdf5Error("data layout class %d (message version %d: v4 chunk indices / virtual datasets) on '%s' "
+                                "not supported; re-save the file with default h5py settings" % (cls, ver, self.name))
+        else:
+            raise Hdf5Error("data layout message version %d on '%s' not supported" % (ver, self.name))
+        if len(raw) < nbytes:
+            raise Hdf5Error("'%s': %d bytes stored, %d expected" % (self.name, len(raw), nbytes))
+        return _decode_values(r, dt, shape, raw[:nbytes])
+
+    def _contiguous(self, addr: int, nbytes: int) -> bytes:
+        if addr == UNDEF:  # never written: fill value (zero) semantics
+            return bytes(nbytes)
+        return self._file._r.bytes(self._file._r.addr(addr), nbytes)
+
+    def _chunked(self, btree: int, rank: int, dims: List[int], nbytes: int) -> bytes:
+        """rank counts the trailing element-size dimension; dims[:-1] is the chunk shape."""
+        r = self._file._r
+        shape = self.shape
+        cshape = tuple(dims[:rank - 1])
+        esize = dims[rank - 1]
+        if len(cshape) != len(shape) or esize != self._dt.size:
+            raise Hdf5Error("'%s': chunk rank/element size disagree with the dataspace" % self.name)
+        out = np.zeros(shape, dtype=np.dtype("V%d" % esize))
+        if btree == UNDEF:
+            return out.tobytes()
+        chunk_bytes = int(np.prod(cshape)) * esize
+
+        def walk(addr: int) -> None:
+            pos = r.addr(addr)
+            if r.bytes(pos, 4) != b"TREE" or r.u(pos + 4, 1) != 1:
+                raise Hdf5Error("'%s': bad chunk B-tree node at %d" % (self.name, addr))
+            level = r.u(pos + 5, 1)
+            n = r.u(pos + 6, 2)
+            p = pos + 8 + 2 * r.O
+            ksz = 8 + 8 * rank
+            for i in range(n):
+                csize = r.u(p, 4)
+                fmask = r.u(p + 4, 4)
+                offs = [r.u(p + 8 + 8 * d, 8) for d in range(rank - 1)]
+                child = r.off(p + ksz)
+                p += ksz + r.O
+                if level > 0:
+                    walk(child)
+                    continue
+                raw = r.bytes(r.addr(child), csize)
+                raw = _unfilter(raw, self._filters, fmask, esize, self.name)
+                if len(raw) < chunk_bytes:
+                    raise Hdf5Error("'%s': short chunk (%d of %d bytes)" % (self.name, len(raw), chunk_bytes))
+                chunk = np.frombuffer(raw[:chunk_bytes], dtype=out.dtype).reshape(cshape)
+                sl_out = tuple(slice(o, min(o + c, s)) for o, c, s in zip(offs, cshape, shape))
+                sl_in = tuple(slice(0, s.stop - s.start) for s in sl_out)
+                out[sl_out] = chunk[sl_in]
+
+        walk(btree)
+        return out.tobytes()
+
+    def __getitem__(self, key):
+        a = self.read()
+        if key is Ellipsis or key == ():
+            return a
+        return a[key]
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.read()
+        return a if dtype is None else a.astype(dtype)
+
+
+def _parse_filters(r: _Reader, pos: int) -> List[Tuple[int, List[int]]]:
+    ver = r.u(pos, 1)
+    n = r.u(pos + 1, 1)
+    out = []
+    if ver == 1:
+        p = pos + 8
+        for _ in range(n):
+            fid, nlen, _flags, ncv = r.u(p, 2), r.u(p + 2, 2), r.u(p + 4, 2), r.u(p + 6, 2)
+            p += 8 + _pad8(nlen)
+            cv = [r.u(p + 4 * i, 4) for i in range(ncv)]
+            p += 4 * ncv + (4 if ncv & 1 else 0)
+            out.append((fid, cv))
+    elif ver == 2:
+        p = pos + 2
+        for _ in range(n):
+            fid = r.u(p, 2)
+            p += 2
+            nlen = 0
+            if fid >= 256:
+                nlen = r.u(p, 2)
+                p += 2
+            _flags, ncv = r.u(p, 2), r.u(p + 2, 2)
+            p += 4 + nlen
+            cv = [r.u(p + 4 * i, 4) for i in range(ncv)]
+            p += 4 * ncv
+            out.append((fid, cv))
+    else:
+        raise Hdf5Error("filter pipeline message version %d not supported" % ver)
+    return out
+
+
+def _unfilter(raw: bytes, filters: List[Tuple[int, List[int]]], mask: int, esize: int, name: str) -> bytes:
+    for i in reversed(range(len(filters))):
+        if mask & (1 << i):
+            continue
+        fid, cv = filters[i]
+        if fid == 1:
+            raw = zlib.decompress(raw)
+        elif fid == 2:
+            sz = cv[0] if cv else esize
+            n = len(raw) // sz
+            body = np.frombuffer(raw[:n * sz], dtype=np.uint8).reshape(sz, n).T.tobytes()
+            raw = body + raw[n * sz:]
+        elif fid == 3:
+            raw = raw[:-4]  # fletcher32 checksum trails the chunk
+        else:
+            raise Hdf5Error("'%s': filter id %d (e.g. szip/lzf/nbit) not supported" % (name, fid))
+    return raw
+
+
+class Group(_Node):
+    def __init__(self, file: "File", addr: int, name: str):
+        super().__init__(file, addr, name)
+        self._links: Optional[Dict[str, int]] = None
+
+    def _load_links(self) -> Dict[str, int]:
+        if self._links is None:
+            r = self._file._r
+            links: Dict[str, int] = {}
+            for mtype, mflags, pos, size in self._msgs:
+                if mtype == MSG_SYMTAB:
+                    links.update(_symtab_links(r, r.off(pos), r.off(pos + r.O)))
+                elif mtype == MSG_LINK:
+                    k, a = _parse_link_message(r, pos)
+                    links[k] = a
+                elif mtype == MSG_LINKINFO:
+                    flags = r.u(pos + 1, 1)
+                    p = pos + 2 + (8 if flags & 1 else 0)
+                    if r.off(p) != UNDEF:
+                        raise Hdf5Error("group '%s' uses dense link storage (fractal heap), not supported; "
+                                        "re-save the file with libver='earliest'" % self.name)
+            self._links = links
+        return self._links
+
+    def keys(self) -> List[str]:
+        return sorted(self._load_links())
+
+    def __iter__(self) -> Iterator[str]:
+        return iter(self.keys())
+
+    def __len__(self) -> int:
+        return len(self._load_links())
+
+    def __contains__(self, path: str) -> bool:
+        try:
+            self[path]
+            return True
+        except KeyError:
+            return False
+
+    def __getitem__(self, path: str):
+        node = self._file.root if path.startswith("/") else self
+        for part in [p for p in path.split("/") if p]:
+            if not isinstance(node, Group):
+                raise KeyError(path)
+            links = node._load_links()
+            if part not in links:
+                raise KeyError("'%s' not found in group '%s'" % (part, node.name))
+            node = node._file._open(links[part], (node.name.rstrip("/") + "/" + part))
+        return node
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def visititems(self, fn: Callable[[str, object], object], _prefix: str = ""):
+        for k, v in self.items():
+            rel = _prefix + k
+            ret = fn(rel, v)
+            if ret is not None:
+                return ret
+            if isinstance(v, Group):
+                ret = v.visititems(fn, rel + "/")
+                if ret is not None:
+                    return ret
+        return None
+
+
+class File(Group):
+    """`File(path)` opens read-only and parses lazily; usable as a context manager like `h5py.File`."""
+
+    def __init__(self, path: str, mode: str = "r"):
+        if mode != "r":
+            raise Hdf5Error("hdf5_lite is read-only")
+        with open(path, "rb") as f:
+            buf = f.read()
+        self._r = _Reader(buf)
+        self._cache: Dict[int, _Node] = {}
+        self.filename = path
+        r = self._r
+        sb = 0
+        while True:
+            if sb + 8 > len(buf):
+                raise Hdf5Error("'%s' is not an HDF5 file (signature not found)" % path)
+            if buf[sb:sb + 8] == SIGNATURE:
+                break
+            sb = 512 if sb == 0 else sb * 2
+        ver = r.u(sb + 8, 1)
+        if ver in (0, 1):
+            r.O, r.L = r.u(sb + 13, 1), r.u(sb + 14, 1)
+            p = sb + 24 + (4 if ver == 1 else 0)
+            r.base = r.off(p)
+            eof = r.off(p + 2 * r.O)
+            p += 4 * r.O
+            root_addr = r.off(p + r.O)  # symbol table entry: name offset, object header address, ...
+        elif ver in (2, 3):
+            r.O, r.L = r.u(sb + 9, 1), r.u(sb + 10, 1)
+            r.base = r.off(sb + 12)
+            eof = r.off(sb + 12 + 2 * r.O)
+            root_addr = r.off(sb + 12 + 3 * r.O)
+        else:
+            raise Hdf5Error("superblock version %d not supported" % ver)
+        if r.O not in (4, 8) or r.L not in (4, 8):
+            raise Hdf5Error("offset/length sizes %d/%d not supported" % (r.O, r.L))
+        if r.base == UNDEF:
+            r.base = 0
+        if eof != UNDEF and r.base + eof > len(buf):
+            raise Hdf5Error("'%s' is truncated: the superblock records %d bytes, the file has %d"
+                            % (path, r.base + eof, len(buf)))
+        self.root = self
+        Group.__init__(self, self, root_addr, "/")
+
+    def _open(self, addr: int, name: str) -> _Node:
+        if addr in self._cache:
+            return self._cache[addr]
+        msgs = _messages(self._r, addr)
+        is_dataset = any(m[0] == MSG_LAYOUT for m in msgs)
+        node: _Node = Dataset(self, addr, name) if is_dataset else Group(self, addr, name)
+        self._cache[addr] = node
+        return node
+
+    def close(self) -> None:
+        pass
+
+    def __enter__(self) -> "File":
+        return self
+
+    def __exit__(self, *exc) -> None:
+        self.close()

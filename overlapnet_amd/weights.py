@@ -8,8 +8,8 @@ weight file keyed by the reference's layer names loads by name exactly as
 Kernel layout is Keras' `(kh, kw, cin, cout)`; Dense kernel is `(in, out)`.
 
 Native container: `.npz` with keys `<layer>/kernel` and `<layer>/bias`.
-A Keras HDF5 file (`model_geo.weight`, written by `training.py:349`) is converted on the fly when
-`h5py` is importable (it is not in the build image).
+A Keras HDF5 file (`model_geo.weight`, written by `training.py:349`) is read directly through the
+dependency-free parser in `hdf5_lite.py` (h5py is not in the ROCm image).
 """
 from __future__ import annotations
 
@@ -157,27 +157,37 @@ def load_npz(path: str) -> Dict[str, np.ndarray]:
 
 
 def load_keras_hdf5(path: str) -> Dict[str, np.ndarray]:
-    """Read a Keras 2.1.x full-model / weights HDF5 by layer name. Needs h5py (absent in the build
-    image) -- the layout is `[model_weights/]<layer>/<layer>/{kernel:0,bias:0}`."""
-    try:
-        import h5py  # type: ignore
-    except ImportError as e:  # pragma: no cover - h5py not in the image
-        raise RuntimeError(
-            "reading the Keras HDF5 weight file '%s' needs h5py; convert it once with "
-            "`python -m overlapnet_amd.weights in.weight out.npz` where h5py is available" % path) from e
+    """Read a Keras 2.1.x full-model (`model.save`, reference `training.py:349`) or weights-only HDF5 file by
+    layer name, the way `load_weights(..., by_name=True)` does (`infer.py:119-120`).
+
+    Layout: `[model_weights/]<layer>/<weight name>` with the layer's `weight_names` attribute listing e.g.
+    `s_conv1/kernel:0`, `s_conv1/bias:0` (so datasets sit at `<layer>/<layer>/kernel:0`).  Parsed by the
+    built-in reader `hdf5_lite` (no h5py needed); layers without weights and the `optimizer_weights`
+    group are skipped."""
+    from . import hdf5_lite
+
     out: Dict[str, np.ndarray] = {}
-    with h5py.File(path, "r") as f:
+    with hdf5_lite.File(path) as f:
         root = f["model_weights"] if "model_weights" in f else f
-        for layer in root:
+        names = root.attrs.get("layer_names")
+        layers = [n.decode("utf8") if isinstance(n, bytes) else str(n) for n in np.asarray(names).ravel()] \
+            if names is not None else root.keys()
+        for layer in layers:
+            if layer not in root:
+                raise Exception("weight file '%s': layer '%s' listed in layer_names has no group" % (path, layer))
             grp = root[layer]
-
-            def visit(name, obj, layer=layer):
-                if hasattr(obj, "shape"):
-                    leaf = name.split("/")[-1].split(":")[0]
-                    if leaf in ("kernel", "bias"):
-                        out["%s/%s" % (layer, leaf)] = np.asarray(obj, np.float32)
-
-            grp.visititems(visit)
+            wnames = grp.attrs.get("weight_names")
+            if wnames is None:  # no attribute: walk the group
+                found: List[str] = []
+                grp.visititems(lambda name, obj: found.append(name) if isinstance(obj, hdf5_lite.Dataset) else None)
+                wnames = found
+            for wn in np.asarray(wnames).ravel():
+                wn = wn.decode("utf8") if isinstance(wn, bytes) else str(wn)
+                leaf = wn.split("/")[-1].split(":")[0]
+                if leaf in ("kernel", "bias"):
+                    out["%s/%s" % (layer, leaf)] = np.ascontiguousarray(grp[wn][()], dtype=np.float32)
+    if not out:
+        raise Exception("weight file '%s' holds no kernel/bias datasets" % path)
     return out
 
 
