@@ -103,6 +103,16 @@ int ovn_spectrum(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* spectra
 int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l_dev, const int32_t* lidx_dev, const float* spec_r_dev,
                            const int32_t* ridx_dev, int64_t n, int32_t* yaw_dev, float* corr_dev, void* stream);
 
+/* Loop-closure decision of a 1-vs-N sweep, on the device (demo/demo3_lcd.py:117-120:
+ * `if np.max(overlaps) > overlap_thres: return reference_idx[np.argmax(overlaps)]`; first maximum wins, NaN never wins).
+ *   overlap_dev (n) f32, yaw_dev (n) i32 or NULL: outputs of ovn_heads / ovn_delta_head (+ ovn_corr_head_spectral)
+ *   ids_dev     (n) i32 candidate ids (reference_idx) or NULL -> position + index_offset (the shard's first candidate)
+ *   out_dev     4 x int32: { id of the best candidate (-1 when n == 0), float bits of its overlap, its yaw,
+ *                            1 if overlap > threshold else 0 }
+ * Ranks of a sharded sweep exchange these 16-byte records instead of N scores (overlapnet_amd/distributed.py). */
+int ovn_best_match(ovn_ctx* ctx, const float* overlap_dev, const int32_t* yaw_dev, const int32_t* ids_dev, int64_t n,
+                   float threshold, int64_t index_offset, int32_t* out_dev, void* stream);
+
 /* Spherical projection + normals for a batch of scans (src/utils/utils.py:59-134 range_projection and
  * :137-186 gen_normal_map; the drivers gen_depth_data.py:24-46 etc. loop over files and call these).
  *   points_dev   concatenated (x,y,z,intensity) float32 points of all scans

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ovn_corr_head": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "ovn_spectrum": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "ovn_corr_head_spectral": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "ovn_best_match": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_int64, _vp, _vp]),
     "ovn_project": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                               C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ovn_normals": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),

@@ -335,6 +335,16 @@ int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, cons
   return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, false, (hipStream_t)stream_);
 }
 
+int ovn_best_match(ovn_ctx* ctx, const float* overlap, const int32_t* yaw, const int32_t* ids, int64_t n, float threshold,
+                   int64_t index_offset, int32_t* out, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_best_match: ctx is NULL");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_best_match: bad n");
+  OVN_REQUIRE(index_offset >= 0 && index_offset + n < (1ll << 31), OVN_ERR_ARG, "ovn_best_match: bad index_offset");
+  OVN_REQUIRE(out != nullptr && (n == 0 || overlap != nullptr), OVN_ERR_ARG, "ovn_best_match: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return ovn_best_match_forward(overlap, yaw, ids, (int)n, threshold, (int)index_offset, out, (hipStream_t)stream);
+}
+
 int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_dev, int n_scans,
                 int64_t max_points_per_scan, int proj_h, int proj_w, double fov_up_deg, double fov_down_deg,
                 double max_range, float* range_dev, float* vertex_dev, float* intensity_dev, int32_t* idx_dev,

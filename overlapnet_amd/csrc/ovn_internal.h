@@ -152,6 +152,8 @@ int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* fea
 // corr_spectral.hip
 int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
+int ovn_best_match_forward(const float* overlap, const int32_t* yaw, const int32_t* ids, int n, float threshold,
+                           int index_offset, int32_t* out, hipStream_t stream);
 int ovn_corr_spectral_forward(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,
                               const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream);
 

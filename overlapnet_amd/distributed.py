@@ -79,3 +79,30 @@ def best_match(overlap: torch.Tensor, yaw: torch.Tensor, threshold: float = 0.3)
     if float(overlap[i]) > threshold:
         return i, float(overlap[i]), int(yaw[i])
     return None
+
+
+def merge_matches(records) -> "torch.Tensor":
+    """Best of per-shard best-match records ((world, 4) int32: {id, float bits of overlap, yaw, found}).
+    Shards are contiguous and ordered by rank, and each record already holds its shard's first maximum, so
+    'largest overlap, lowest rank on ties' reproduces np.argmax over the whole pool (demo3_lcd.py:119-120).
+    Empty shards carry id -1."""
+    rec = records.reshape(-1, 4).to(torch.int32).cpu()
+    best = None
+    for r in rec:
+        if int(r[0]) < 0:
+            continue
+        v = float(r[1:2].view(torch.float32)[0])
+        if best is None or v > best[0]:
+            best = (v, r)
+    if best is None:
+        return torch.tensor([-1, 0, 0, 0], dtype=torch.int32)
+    return best[1].clone()
+
+
+def best_match_sharded(record: torch.Tensor, group=None) -> "torch.Tensor":
+    """All-gather the 16-byte per-rank records of `OvnEngine.best_match` (RCCL on GPU tensors, gloo on CPU tensors)
+    and merge: every rank gets the global decision; only world x 16 bytes cross xGMI instead of N scores."""
+    world = dist.get_world_size(group)
+    bufs = [torch.empty_like(record) for _ in range(world)]
+    dist.all_gather(bufs, record.contiguous(), group=group)
+    return merge_matches(torch.stack([b.cpu() for b in bufs]))

@@ -218,6 +218,23 @@ class OvnEngine:
                                                        _ptr(yaw), _ptr(corr), self._stream()), "ovn_corr_head_spectral")
         return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
 
+    # -- loop-closure decision -----------------------------------------------------------------------
+    def best_match(self, overlap: torch.Tensor, yaw: Optional[torch.Tensor] = None, threshold: float = 0.3,
+                   ids: Optional[torch.Tensor] = None, index_offset: int = 0) -> torch.Tensor:
+        """On-device `argmax overlap, > threshold` of demo3 (demo3_lcd.py:117-120).  Returns a 4 x int32 device
+        record {candidate id, float bits of overlap, yaw, found}; decode with `decode_match`."""
+        n = int(overlap.numel())
+        for t, what, dt in ((overlap, "overlap", torch.float32), (yaw, "yaw", torch.int32), (ids, "ids", torch.int32)):
+            if t is None:
+                continue
+            if t.device != self.device or t.dtype != dt or not t.is_contiguous() or t.numel() != n:
+                raise _lib.OvnError("%s must be a contiguous %s tensor of %d elements on %s" % (what, dt, n, self.device))
+        out = torch.empty(4, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_best_match(self._h, _ptr(overlap), _ptr(yaw), _ptr(ids), n, float(threshold),
+                                               int(index_offset), _ptr(out), self._stream()), "ovn_best_match")
+        return out
+
     # -- preprocessing ------------------------------------------------------------------------------
     def project(self, points: torch.Tensor, offsets: torch.Tensor, max_points: int, proj_h: int = 64,
                 proj_w: int = 900, fov_up: float = 3.0, fov_down: float = -25.0, max_range: float = 50.0,
@@ -313,3 +330,13 @@ class OvnEngine:
 
     def workspace_bytes(self) -> int:
         return int(self.lib.ovn_workspace_bytes(self._h))
+
+
+def decode_match(record) -> Optional[Tuple[int, float, int]]:
+    """(candidate id, overlap, yaw) from a best-match record, or None when nothing exceeded the threshold."""
+    import numpy as np
+
+    r = np.asarray(record.cpu() if hasattr(record, "cpu") else record, dtype=np.int32).reshape(4)
+    if r[3] == 0 or r[0] < 0:
+        return None
+    return int(r[0]), float(r[1:2].view(np.float32)[0]), int(r[2])

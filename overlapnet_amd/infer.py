@@ -6,7 +6,8 @@ types and error behaviour; the Keras/TensorFlow models behind it are replaced by
   * feature volumes additionally stay resident in HBM between calls (`infer_multiple` never
     re-uploads the cache the way `infer.py:192-193` rebuilds `np.array(self.feature_volumes)`);
   * `pretrained_weightsfilename` may name a native `.npz` (keys `<layer>/kernel|bias`) besides the
-    Keras HDF5 file (the latter needs h5py);
+    Keras HDF5 file (read by the built-in `hdf5_lite` parser);
+  * `infer_best_match` (extension): `infer_multiple` + demo3's decision taken on the GPU;
   * `self.leg` / `self.head` are the native engine, not keras.Model objects.
 """
 from __future__ import annotations
@@ -225,6 +226,25 @@ class Infer():
       return overlap.squeeze(), yaw
     else:
       return None
+
+  def infer_best_match(self, current_frame_id, reference_frame_id, overlap_thres=0.3):
+    """ Addition to the reference API: `infer_multiple` + the loop-closure decision of demo3
+        (demo3_lcd.py:117-120) taken on the GPU, so only one record crosses PCIe instead of N scores.
+        Returns (reference frame id, overlap, yaw) or None; caches the current frame like `infer_multiple`. """
+    from .engine import decode_match
+    filename = [str(current_frame_id).zfill(6)]
+    fv = self._leg_device(filename)
+    self.feature_volumes.append(fv[0].cpu().numpy().reshape(1, FEAT_W, FEAT_C))
+    self._append_device(fv)
+    if len(reference_frame_id) == 0:
+      return None
+    ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
+    if ref.min() < 0 or max(int(ref.max()), int(current_frame_id)) >= self._dev_n:
+      raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(ref.max()), self._dev_n))
+    feats = self._dev_fv[:self._dev_n]
+    ids = torch.from_numpy(ref.astype(np.int32)).to(self.engine.device)
+    r = self.engine.heads(feats, feats, lidx=ids, ridx=np.full(len(ref), int(current_frame_id)))
+    return decode_match(self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=ids))
 
   def infer_multiple_vs_multiple(self, file_names, first_idxs, second_idxs):
     """ Multiple pairs (infer.py:205-238): pair i = (file_names[first_idxs[i]], file_names[second_idxs[i]]);

@@ -70,6 +70,8 @@ def detect(infer, idx: int, traj_xy: np.ndarray, traj_length: np.ndarray, ellips
     volume, demo3_lcd.py:88-90,122) and returns the loop-closure decision."""
     overlap_thres = gate_kw.pop("overlap_thres", 0.3)
     ref = gate_candidates(idx, traj_xy, traj_length, ellipse, **gate_kw)
+    if hasattr(infer, "infer_best_match"):  # decision taken on the GPU, one record returned
+        return infer.infer_best_match(idx, list(ref), overlap_thres)
     res = infer.infer_multiple(idx, list(ref))
     if res is None:
         return None

@@ -76,3 +76,66 @@ def test_gather_world2_gloo(n_total):
     assert ok
     if n_total > 0:
         assert bm_ok
+
+
+def _record(idx, ov, yaw, thr):
+    r = torch.zeros(4, dtype=torch.int32)
+    if idx < 0:
+        r[0] = -1
+        return r
+    r[0] = idx
+    r[1:2] = torch.tensor([ov], dtype=torch.float32).view(torch.int32)
+    r[2] = yaw
+    r[3] = 1 if ov > thr else 0
+    return r
+
+
+def _host_best(ov, yaw, lo, thr):
+    """What OvnEngine.best_match computes on the device (first maximum wins), restated on the host."""
+    if ov.numel() == 0:
+        return _record(-1, 0, 0, thr)
+    k = int(torch.argmax(ov))           # torch.argmax: first maximum, like np.argmax
+    k = int((ov == ov[k]).nonzero()[0])
+    return _record(lo + k, float(ov[k]), int(yaw[k]), thr)
+
+
+def test_merge_matches_first_maximum_and_empty_shards():
+    thr = 0.3
+    recs = torch.stack([_record(-1, 0, 0, thr), _record(7, 0.5, 3, thr), _record(12, 0.5, -4, thr), _record(20, 0.2, 9, thr)])
+    m = D.merge_matches(recs)
+    assert m.tolist()[0] == 7 and m.tolist()[2] == 3 and m.tolist()[3] == 1      # tie -> lower rank = lower index
+    assert D.merge_matches(torch.stack([_record(-1, 0, 0, thr)] * 3)).tolist() == [-1, 0, 0, 0]
+    low = D.merge_matches(torch.stack([_record(1, 0.1, 5, thr), _record(9, 0.25, 6, thr)]))
+    assert low.tolist()[0] == 9 and low.tolist()[3] == 0                          # best is reported, not accepted
+
+
+def _worker_match(rank, world, port, n_total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(n_total)
+        all_ov = torch.from_numpy((rng.integers(0, 50, n_total) / 50.0).astype(np.float32))   # many exact ties
+        all_yaw = torch.from_numpy(rng.integers(-179, 181, n_total).astype(np.int32))
+        lo, hi = D.shard_bounds(n_total, world, rank)
+        local = _host_best(all_ov[lo:hi], all_yaw[lo:hi], lo, 0.3)
+        got = D.best_match_sharded(local)
+        want = _host_best(all_ov, all_yaw, 0, 0.3)
+        q.put((rank, got.tolist() == want.tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [0, 1, 3, 1000])
+def test_best_match_sharded_world2_gloo(n_total):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_match, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}          # every rank holds the same, correct decision

@@ -366,6 +366,17 @@ def test_infer_class_end_to_end(tmp_path, fixture_npz):
     assert ov3.shape == (3,) and np.max(np.abs(ov3 - o_ov)) < 1e-4 and np.array_equal(yaw3, o_yaw)
     assert len(inf.feature_volumes) == 4 and inf.feature_volumes[0].shape == (1, 360, 128)
 
+    # extension: the same sweep with demo3's decision (demo3_lcd.py:117-120) taken on the device
+    from overlapnet_amd import lcd
+    inf2 = Infer(dict(cfg, model=dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900])), weights=w)
+    for i in range(3):
+        assert inf2.infer_best_match(i, []) is None
+    want = lcd.decide([0, 1, 2], ov3, yaw3, 0.0)
+    got = inf2.infer_best_match(3, [0, 1, 2], overlap_thres=0.0)
+    assert got[0] == want[0] and got[2] == want[2] and got[1] == np.float32(want[1])
+    assert len(inf2.feature_volumes) == 4
+    assert inf2.infer_best_match(4 - 1, [2, 0], overlap_thres=2.0) is None    # nothing above the threshold
+
     # infer_multiple_vs_multiple: l = second_idxs, r = first_idxs
     names = ["000000", "000001.bin", "d/000003.bin"]
     ovm, yawm = inf.infer_multiple_vs_multiple(names, [0, 1, 2], [2, 1, 1])
@@ -378,6 +389,34 @@ def test_infer_class_end_to_end(tmp_path, fixture_npz):
     cfg_bad = dict(cfg, model=dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900], legsType="360OutputkLegs_smaller"))
     with pytest.raises(AttributeError):
         Infer(cfg_bad, weights=w)
+
+
+def test_best_match_on_device(engines):
+    """ovn_best_match == `np.argmax` + threshold of demo3_lcd.py:117-120 (first maximum wins), bit-exact."""
+    from overlapnet_amd.engine import decode_match
+    e = engines[4]
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 63, 64, 65, 1023, 1024, 1025, 4097, 100003):
+        ov = (rng.integers(0, 97, n) / 97.0).astype(np.float32)            # plenty of exact ties
+        yaw = rng.integers(-179, 181, n).astype(np.int32)
+        ids = rng.permutation(n).astype(np.int32)
+        t_ov, t_yaw, t_ids = (torch.from_numpy(a).cuda() for a in (ov, yaw, ids))
+        k = int(np.argmax(ov))
+        for thr in (0.3, 0.999):
+            want = (k, float(ov[k]), int(yaw[k])) if ov[k] > thr else None
+            assert decode_match(e.best_match(t_ov, t_yaw, thr)) == want
+            rec = e.best_match(t_ov, t_yaw, thr, ids=t_ids).cpu().numpy()
+            assert rec[0] == ids[k] and rec[1:2].view(np.float32)[0] == ov[k] and rec[2] == yaw[k] and rec[3] == int(ov[k] > thr)
+        assert e.best_match(t_ov, t_yaw, 0.0, index_offset=1000).cpu().numpy()[0] == 1000 + k
+        assert e.best_match(t_ov, None, 0.0).cpu().numpy()[2] == 0           # yaw optional
+    # NaN never wins; all-NaN and empty inputs report "nothing"
+    ov = np.array([np.nan, 0.4, np.nan, 0.7, 0.7], np.float32)
+    rec = e.best_match(torch.from_numpy(ov).cuda(), torch.arange(5, dtype=torch.int32).cuda(), 0.3).cpu().numpy()
+    assert rec.tolist()[0] == 3 and rec[3] == 1
+    assert e.best_match(torch.full((7,), float("nan")).cuda(), None, 0.3).cpu().tolist() == [-1, 0, 0, 0]
+    assert decode_match(e.best_match(torch.empty(0).cuda(), None, 0.3)) is None
+    with pytest.raises(Exception, match="yaw must be"):
+        e.best_match(torch.zeros(4).cuda(), torch.zeros(3, dtype=torch.int32).cuda())
 
 
 def test_spectral_correlation_head(engines):
