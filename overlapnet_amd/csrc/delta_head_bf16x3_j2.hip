@@ -27,14 +27,20 @@ constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + 2 * (size_t)S * FC 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// |d0|, |d1| -> packed bf16 pairs (element 0 in the low half).  hi = |d| truncated to bf16 (one AND also strips
-// the sign), lo = bf16_rne(|d| - hi): |d| - hi is exact in fp32, so hi + lo carries |d| to ~2^-17 relative.
-__device__ __forceinline__ void split_pair(float d0, float d1, unsigned& hi_pk, unsigned& lo_pk) {
-  const unsigned h0 = __float_as_uint(d0) & 0x7fff0000u;
-  const unsigned h1 = __float_as_uint(d1) & 0x7fff0000u;
-  const float l0 = fabsf(d0) - __uint_as_float(h0);
-  const float l1 = fabsf(d1) - __uint_as_float(h1);
-  hi_pk = (h0 >> 16) | h1;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (l0 - r0, l1 - r1) -> |.| as packed bf16 pairs (element 0 in the low half).  hi = |d| truncated to bf16 (one AND
+// also strips the sign), lo = bf16_rne(|d| - hi): |d| - hi is exact in fp32, so hi + lo carries |d| to ~2^-17 relative.
+// 7 VALU instructions per pair: the split competes with the MFMAs for issue slots (tools/experiments/ubench3.hip:
+// an MFMA hides only ~40 % of the VALU time next to it), so every instruction counts: the two subtractions go through
+// one packed-fp32 add (L and R pairs sit in aligned register pairs) and the hi halves are packed by one v_perm_b32.
+__device__ __forceinline__ void split_pair(f32x2 l, f32x2 r, unsigned& hi_pk, unsigned& lo_pk) {
+  const f32x2 d = l - r;
+  const unsigned h0 = __float_as_uint(d[0]) & 0x7fff0000u;
+  const unsigned h1 = __float_as_uint(d[1]) & 0x7fff0000u;
+  const float l0 = fabsf(d[0]) - __uint_as_float(h0);
+  const float l1 = fabsf(d[1]) - __uint_as_float(h1);
+  hi_pk = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 lp;
   lp[0] = (__bf16)l0;
@@ -46,10 +52,10 @@ __device__ __forceinline__ void split_pair(float d0, float d1, unsigned& hi_pk, 
 __device__ __forceinline__ void make_a(const f32x4& l0, const f32x4& l1, const f32x4& r0, const f32x4& r1, bf16x8& ah,
                                        bf16x8& al) {
   unsigned h0, h1, h2, h3, q0, q1, q2, q3;
-  split_pair(l0[0] - r0[0], l0[1] - r0[1], h0, q0);
-  split_pair(l0[2] - r0[2], l0[3] - r0[3], h1, q1);
-  split_pair(l1[0] - r1[0], l1[1] - r1[1], h2, q2);
-  split_pair(l1[2] - r1[2], l1[3] - r1[3], h3, q3);
+  split_pair((f32x2){l0[0], l0[1]}, (f32x2){r0[0], r0[1]}, h0, q0);
+  split_pair((f32x2){l0[2], l0[3]}, (f32x2){r0[2], r0[3]}, h1, q1);
+  split_pair((f32x2){l1[0], l1[1]}, (f32x2){r1[0], r1[1]}, h2, q2);
+  split_pair((f32x2){l1[2], l1[3]}, (f32x2){r1[2], r1[3]}, h3, q3);
   ah = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
   al = __builtin_bit_cast(bf16x8, (u32x4){q0, q1, q2, q3});
 }
@@ -205,11 +211,12 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     for (int j = 0; j < 2; ++j) {
     const int jb = 2 * jb2 + j;
     if (j == 1) __syncthreads();  // GEMM2 of the first group is done with the o1 image
-    // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
+    // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout (K order k' = di*64 + 4*lrow + nt, see the W2 prep kernel).
+    // C/D: lane holds column lrow of every n-tile, rows 4g..4g+3: one 8-byte store for the 4 hi parts, one for the lo parts.
+    {
+      float bv[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int o = 16 * nt + lrow;
-      const float bv = b1[o];
+      for (int nt = 0; nt < 4; ++nt) bv[nt] = b1[16 * nt + lrow];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -218,10 +225,17 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
           if (i < FW) {
             const int ib = i / S;
             const int di = i - ib * S;
-            __bf16 h, l;
-            split_bf16(acc[j][t][nt][r] + bv, h, l);
-            o1h[ib * O1_STRIDE + di * O1 + o] = h;
-            o1l[ib * O1_STRIDE + di * O1 + o] = l;
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 h4, l4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              __bf16 h, l;
+              split_bf16(acc[j][t][nt][r] + bv[nt], h, l);
+              h4[nt] = h;
+              l4[nt] = l;
+            }
+            *reinterpret_cast<bf16x4*>(o1h + ib * O1_STRIDE + di * O1 + 4 * lrow) = h4;
+            *reinterpret_cast<bf16x4*>(o1l + ib * O1_STRIDE + di * O1 + 4 * lrow) = l4;
           }
         }
       }
@@ -242,24 +256,44 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
-#pragma unroll 6
-      for (int kk = 0; kk < K2 / 32; ++kk) {
-        int ks = kk + ks0;
-        if (ks >= K2 / 32) ks -= K2 / 32;
-        const __bf16* wk = wcol + (size_t)ks * (8 * 2 * 512);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wk);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wk + 512);
-        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);
-        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);
-        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);
-        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);
-        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, acc2[1], 0, 0, 0);
-        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, acc2[1], 0, 0, 0);
-        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, acc2[1], 0, 0, 0);
+      // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
+      // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
+      constexpr int GB = 5, NB = K2 / 32 / GB;
+      static_assert(NB % 2 == 0, "the batch loop is unrolled by two");
+      bf16x8 wq0[GB][2], wq1[GB][2];
+      auto ksof = [&](int kk) { const int ks = kk + ks0; return ks >= K2 / 32 ? ks - K2 / 32 : ks; };
+#define OVN_W2_LOAD(DST, B)                                                        \
+  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
+    const __bf16* wk = wcol + (size_t)ksof((B) * GB + u) * (8 * 2 * 512);          \
+    DST[u][0] = *reinterpret_cast<const bf16x8*>(wk);                              \
+    DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512);                        \
+  }
+#define OVN_W2_COMPUTE(SRC, B)                                                     \
+  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
+    const int ks = ksof((B) * GB + u);                                             \
+    const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);            \
+    const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);            \
+    const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);            \
+    const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);            \
+    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][0], acc2[0], 0, 0, 0); \
+    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][0], acc2[1], 0, 0, 0); \
+    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, SRC[u][0], acc2[0], 0, 0, 0); \
+    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, SRC[u][0], acc2[1], 0, 0, 0); \
+    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][1], acc2[0], 0, 0, 0); \
+    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][1], acc2[1], 0, 0, 0); \
+  }
+      OVN_W2_LOAD(wq0, 0)
+#pragma unroll 1
+      for (int b = 0; b < NB; b += 2) {
+        OVN_W2_LOAD(wq1, b + 1)
+        OVN_W2_COMPUTE(wq0, b)
+        if (b + 2 < NB) {
+          OVN_W2_LOAD(wq0, b + 2)
+        }
+        OVN_W2_COMPUTE(wq1, b + 1)
       }
+#undef OVN_W2_LOAD
+#undef OVN_W2_COMPUTE
       const int p = 16 * wave + lrow;
       const float bv = b2[p];
 #pragma unroll
