@@ -1,5 +1,5 @@
-// Timing ablations of the shipped two-group Delta kernel (generated from overlapnet_amd/csrc/delta_head_bf16x3_j2.hip by
-// tools/experiments/make_delta_j2_ablate.py; results are WRONG by construction, only the timings mean anything).
+// Timing ablations of the shipped two-group Delta kernel, generated from overlapnet_amd/csrc/delta_head_bf16x3_j2.hip by
+// tools/experiments/make_delta_j2_ablate.py (results are WRONG by construction, only the timings mean anything).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #define OVN_FEAT_W 360
@@ -30,14 +30,20 @@ constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + 2 * (size_t)S * FC 
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// |d0|, |d1| -> packed bf16 pairs (element 0 in the low half).  hi = |d| truncated to bf16 (one AND also strips
-// the sign), lo = bf16_rne(|d| - hi): |d| - hi is exact in fp32, so hi + lo carries |d| to ~2^-17 relative.
-__device__ __forceinline__ void split_pair(float d0, float d1, unsigned& hi_pk, unsigned& lo_pk) {
-  const unsigned h0 = __float_as_uint(d0) & 0x7fff0000u;
-  const unsigned h1 = __float_as_uint(d1) & 0x7fff0000u;
-  const float l0 = fabsf(d0) - __uint_as_float(h0);
-  const float l1 = fabsf(d1) - __uint_as_float(h1);
-  hi_pk = (h0 >> 16) | h1;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (l0 - r0, l1 - r1) -> |.| as packed bf16 pairs (element 0 in the low half).  hi = |d| truncated to bf16 (one AND
+// also strips the sign), lo = bf16_rne(|d| - hi): |d| - hi is exact in fp32, so hi + lo carries |d| to ~2^-17 relative.
+// 7 VALU instructions per pair: the split competes with the MFMAs for issue slots (tools/experiments/ubench3.hip:
+// an MFMA hides only ~40 % of the VALU time next to it), so every instruction counts: the two subtractions go through
+// one packed-fp32 add (L and R pairs sit in aligned register pairs) and the hi halves are packed by one v_perm_b32.
+__device__ __forceinline__ void split_pair(f32x2 l, f32x2 r, unsigned& hi_pk, unsigned& lo_pk) {
+  const f32x2 d = l - r;
+  const unsigned h0 = __float_as_uint(d[0]) & 0x7fff0000u;
+  const unsigned h1 = __float_as_uint(d[1]) & 0x7fff0000u;
+  const float l0 = fabsf(d[0]) - __uint_as_float(h0);
+  const float l1 = fabsf(d[1]) - __uint_as_float(h1);
+  hi_pk = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
   typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
   bf16x2 lp;
   lp[0] = (__bf16)l0;
@@ -49,10 +55,10 @@ __device__ __forceinline__ void split_pair(float d0, float d1, unsigned& hi_pk, 
 __device__ __forceinline__ void make_a(const f32x4& l0, const f32x4& l1, const f32x4& r0, const f32x4& r1, bf16x8& ah,
                                        bf16x8& al) {
   unsigned h0, h1, h2, h3, q0, q1, q2, q3;
-  split_pair(l0[0] - r0[0], l0[1] - r0[1], h0, q0);
-  split_pair(l0[2] - r0[2], l0[3] - r0[3], h1, q1);
-  split_pair(l1[0] - r1[0], l1[1] - r1[1], h2, q2);
-  split_pair(l1[2] - r1[2], l1[3] - r1[3], h3, q3);
+  split_pair((f32x2){l0[0], l0[1]}, (f32x2){r0[0], r0[1]}, h0, q0);
+  split_pair((f32x2){l0[2], l0[3]}, (f32x2){r0[2], r0[3]}, h1, q1);
+  split_pair((f32x2){l1[0], l1[1]}, (f32x2){r1[0], r1[1]}, h2, q2);
+  split_pair((f32x2){l1[2], l1[3]}, (f32x2){r1[2], r1[3]}, h3, q3);
   ah = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
   al = __builtin_bit_cast(bf16x8, (u32x4){q0, q1, q2, q3});
 }
@@ -70,7 +76,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
                                                                const __bf16* __restrict__ w1p,
                                                                const float* __restrict__ b1,
                                                                const __bf16* __restrict__ w2p,
-                                                               const float* __restrict__ b2, float* __restrict__ o2, int rot, int prio) {
+                                                               const float* __restrict__ b2, float* __restrict__ o2, int rot) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* o1h = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* o1l = o1h + G * O1_STRIDE;
@@ -83,12 +89,6 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
   const int wave = tid >> 6;
   const int lrow = lane & 15;
   const int g = lane >> 4;
-  // Two waves share each SIMD.  With equal priority the round-robin arbiter keeps them in lock step: both split
-  // (matrix pipe idle), then both issue MFMAs (VALU idle).  Unequal priority lets one run ahead so that one wave's
-  // split overlaps the other's MFMAs.
-  if (prio == 1 && (wave & 4)) __builtin_amdgcn_s_setprio(2);
-  if (prio == 2 && (wave & 1)) __builtin_amdgcn_s_setprio(2);
-  if (prio == 3 && (wave & 2)) __builtin_amdgcn_s_setprio(2);
 
   const float* L = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
   const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
@@ -130,7 +130,6 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     *reinterpret_cast<f32x4*>(wst + (q * NT_ + tid) * 16) = pf[q];
   }
   int cur = 0;
-  f32x4 fake0 = la[0][0], fake1 = la[0][1];
   bf16x8 fakeb = __builtin_bit_cast(bf16x8, la[1][0]);
   int chunk = 5 * s0;  // running chunk index 0..19 (cyclic), 5 chunks per slice
 
@@ -170,12 +169,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
         const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
         const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
         const float* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                     \
-        f32x4 ra0, ra1, rb0, rb1;                                                                                 \
-        if (ABL & 4) { ra0 = fake0; ra1 = fake1; rb0 = fake1; rb1 = fake0; fake0[0] += 1.0f; } else {              \
-        ra0 = *reinterpret_cast<const f32x4*>(rrow);                                                              \
-        ra1 = *reinterpret_cast<const f32x4*>(rrow + 4);                                                          \
-        rb0 = *reinterpret_cast<const f32x4*>(rrow + S * FC);                                                     \
-        rb1 = *reinterpret_cast<const f32x4*>(rrow + S * FC + 4); }                                               \
+        const f32x4 ra0 = *reinterpret_cast<const f32x4*>(rrow);                                                  \
+        const f32x4 ra1 = *reinterpret_cast<const f32x4*>(rrow + 4);                                              \
+        const f32x4 rb0 = *reinterpret_cast<const f32x4*>(rrow + S * FC);                                         \
+        const f32x4 rb1 = *reinterpret_cast<const f32x4*>(rrow + S * FC + 4);                                     \
         bf16x8 bh[4], bl[4];                                                                                      \
         _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
           if (ABL & 8) { bh[nt] = fakeb; bl[nt] = fakeb; } else {                                                 \
@@ -242,11 +239,12 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     for (int j = 0; j < 2; ++j) {
     const int jb = 2 * jb2 + j;
     if (j == 1) __syncthreads();  // GEMM2 of the first group is done with the o1 image
-    // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout.  C/D: lane holds column lrow, rows 4g..4g+3.
+    // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout (K order k' = di*64 + 4*lrow + nt, see the W2 prep kernel).
+    // C/D: lane holds column lrow of every n-tile, rows 4g..4g+3: one 8-byte store for the 4 hi parts, one for the lo parts.
+    {
+      float bv[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      const int o = 16 * nt + lrow;
-      const float bv = b1[o];
+      for (int nt = 0; nt < 4; ++nt) bv[nt] = b1[16 * nt + lrow];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
 #pragma unroll
@@ -255,10 +253,17 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
           if (i < FW) {
             const int ib = i / S;
             const int di = i - ib * S;
-            __bf16 h, l;
-            split_bf16(acc[j][t][nt][r] + bv, h, l);
-            o1h[ib * O1_STRIDE + di * O1 + o] = h;
-            o1l[ib * O1_STRIDE + di * O1 + o] = l;
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 h4, l4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              __bf16 h, l;
+              split_bf16(acc[j][t][nt][r] + bv[nt], h, l);
+              h4[nt] = h;
+              l4[nt] = l;
+            }
+            *reinterpret_cast<bf16x4*>(o1h + ib * O1_STRIDE + di * O1 + 4 * lrow) = h4;
+            *reinterpret_cast<bf16x4*>(o1l + ib * O1_STRIDE + di * O1 + 4 * lrow) = l4;
           }
         }
       }
@@ -279,24 +284,44 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
-#pragma unroll 6
-      for (int kk = 0; kk < K2 / 32; ++kk) {
-        int ks = kk + ks0;
-        if (ks >= K2 / 32) ks -= K2 / 32;
-        const __bf16* wk = wcol + (size_t)ks * (8 * 2 * 512);
-        const bf16x8 bh = *reinterpret_cast<const bf16x8*>(wk);
-        const bf16x8 bl = *reinterpret_cast<const bf16x8*>(wk + 512);
-        const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);
-        const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);
-        const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);
-        const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);
-        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bh, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bh, acc2[1], 0, 0, 0);
-        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, bh, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, bh, acc2[1], 0, 0, 0);
-        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, bl, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, bl, acc2[1], 0, 0, 0);
+      // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
+      // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
+      constexpr int GB = 5, NB = K2 / 32 / GB;
+      static_assert(NB % 2 == 0, "the batch loop is unrolled by two");
+      bf16x8 wq0[GB][2], wq1[GB][2];
+      auto ksof = [&](int kk) { const int ks = kk + ks0; return ks >= K2 / 32 ? ks - K2 / 32 : ks; };
+#define OVN_W2_LOAD(DST, B)                                                        \
+  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
+    const __bf16* wk = wcol + (size_t)ksof((B) * GB + u) * (8 * 2 * 512);          \
+    DST[u][0] = *reinterpret_cast<const bf16x8*>(wk);                              \
+    DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512);                        \
+  }
+#define OVN_W2_COMPUTE(SRC, B)                                                     \
+  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
+    const int ks = ksof((B) * GB + u);                                             \
+    const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);            \
+    const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);            \
+    const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);            \
+    const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);            \
+    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][0], acc2[0], 0, 0, 0); \
+    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][0], acc2[1], 0, 0, 0); \
+    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, SRC[u][0], acc2[0], 0, 0, 0); \
+    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, SRC[u][0], acc2[1], 0, 0, 0); \
+    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][1], acc2[0], 0, 0, 0); \
+    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][1], acc2[1], 0, 0, 0); \
+  }
+      OVN_W2_LOAD(wq0, 0)
+#pragma unroll 1
+      for (int b = 0; b < NB; b += 2) {
+        OVN_W2_LOAD(wq1, b + 1)
+        OVN_W2_COMPUTE(wq0, b)
+        if (b + 2 < NB) {
+          OVN_W2_LOAD(wq0, b + 2)
+        }
+        OVN_W2_COMPUTE(wq1, b + 1)
       }
+#undef OVN_W2_LOAD
+#undef OVN_W2_COMPUTE
       const int p = 16 * wave + lrow;
       const float bv = b2[p];
 #pragma unroll
@@ -328,10 +353,10 @@ int run(const char* what, int n, const float* fl, const float* fr, const __bf16*
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1, 0);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1, 0);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -359,17 +384,11 @@ int main() {
 #define RUN(A, W) if (run<A>(W, n, fl, fr, w1, b1, w2, b2, o2)) return 1;
   RUN(0, "baseline")
   RUN(64, "no epilogue/GEMM2")
-  RUN(64 + 1, "+ no W1 staging")
-  RUN(64 + 1 + 2, "+ no slice barriers")
-  RUN(64 + 1 + 2 + 128, "+ no L reloads")
-  RUN(64 + 1 + 2 + 128 + 4, "+ no R LDS reads")
-  RUN(64 + 1 + 2 + 128 + 4 + 8, "+ no B LDS reads (split + MFMA only)")
-  RUN(64 + 1 + 2 + 128 + 4 + 8 + 16, "+ no split (MFMA only)")
-  RUN(64 + 1 + 2 + 128 + 4 + 8 + 32, "split only (no MFMA, no LDS)")
-  RUN(64 + 16, "full loop, no split")
-  RUN(64 + 32, "full loop, no MFMA")
-  RUN(64 + 2, "full loop, no slice barriers (racy)")
-  RUN(64 + 8, "full loop, no B reads")
-  RUN(64 + 4, "full loop, no R reads")
+  RUN(64 + 1, "no epilogue, no W1 staging")
+  RUN(64 + 1 + 2, "no epilogue, no staging, no slice barriers")
+  RUN(64 + 1 + 2 + 128, "... + no L reloads")
+  RUN(64 + 8, "no epilogue, no B LDS reads")
+  RUN(64 + 16, "no epilogue, no split")
+  RUN(64 + 32, "no epilogue, no MFMA")
   return 0;
 }
