@@ -426,7 +426,8 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
   OVN_REQUIRE(in_dev && out_dev && nb >= 0, OVN_ERR_ARG, "ovn_debug_conv: bad buffers");
   OVN_HIP_CHECK(hipSetDevice(ctx->device));
   int oh = 0, ow = 0;
-  return ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
+  return (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream)
+                              : ovn_conv_forward_bf16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
 }
 
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream) {

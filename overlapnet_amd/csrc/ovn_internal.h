@@ -72,7 +72,7 @@ struct ovn_ctx {
   OvnConvLayer c3;       // c_conv3 as a regular conv layer
   void* w1p_bf = nullptr;  // c_conv1 hi/lo bf16 fragments (delta_head_bf16x3.hip)
   void* w2p_bf = nullptr;  // c_conv2 hi/lo bf16 fragments
-  int leg_mode = 0;        // 0 = fp32 MFMA, 1 = 3-term bf16 split (conv_bf16x3.hip)
+  int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = 3-term bf16 split on the bf16 MFMA (conv_bf16x3.hip)
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = 3-term bf16 split on the bf16 MFMA
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]

@@ -44,7 +44,7 @@ class OvnEngine:
         self._leg_ready = False
         self._head_ready = False
         self.head_precision = "bf16x3"
-        self.leg_precision = "f32"
+        self.leg_precision = "bf16x3"
 
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:

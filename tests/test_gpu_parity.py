@@ -1,7 +1,8 @@
 """GPU (MI355X): the HIP path, called through the C ABI, against the CPU oracle and the golden vectors.
 
 Tolerances (north star: |d overlap| <= 1e-4, exact yaw bin):
-  * activations / corr vectors: max |gpu - fp64 oracle| <= 2e-5 * max|oracle|   (fp32 accumulate)
+  * activations / corr vectors: max |gpu - fp64 oracle| <= 2e-5 * max|oracle| in fp32 mode, 5e-5 (leg) / 6e-5 (head) in the
+    default bf16x3 mode (3-term bf16 split, fp32 accumulate)
   * logit: |d| <= 1e-3 * (1 + |logit|);  overlap: |d| <= 1e-4;  yaw: identical bin unless the oracle's
     own top-2 gap is below 1e-5 relative (reported, not failed)
   * projection: bit-identical images except <= 8 pixels per scan (float32 trig ulps at bin edges)
@@ -80,13 +81,16 @@ def test_each_leg_layer_against_oracle(C):
         oh, ow = (h - l.kh) // l.sh + 1, (wd - l.kw) // l.sw + 1
         xt = torch.from_numpy(x).cuda()
         out = torch.empty((nb, oh, ow, l.cout), dtype=torch.float32, device="cuda")
-        rc = lib.ovn_debug_conv(eng._h, 0, _ptr(xt), nb, h, wd, _ptr(out), st)
-        _lib.check(rc, "ovn_debug_conv")
-        torch.cuda.synchronize()
         ref = O._conv_valid(torch.from_numpy(x.astype(np.float64)).permute(0, 3, 1, 2), k, b, (l.sh, l.sw), True,
                             torch.float64).permute(0, 2, 3, 1).numpy()
-        err = _rel(out.cpu().numpy(), ref)
-        assert err < 2e-5, "%s (C=%d): rel err %.3g" % (l.name, C, err)
+        for mode in ("f32", "bf16x3"):          # both conv kernels (conv_f32.hip, conv_bf16x3.hip)
+            eng.set_leg_precision(mode)
+            out.fill_(float("nan"))
+            rc = lib.ovn_debug_conv(eng._h, 0, _ptr(xt), nb, h, wd, _ptr(out), st)
+            _lib.check(rc, "ovn_debug_conv")
+            torch.cuda.synchronize()
+            err = _rel(out.cpu().numpy(), ref)
+            assert err < 2e-5, "%s (C=%d, %s): rel err %.3g" % (l.name, C, mode, err)
         eng.close()
         h, wd = oh, ow
     assert (h, wd) == (1, 360)
@@ -95,8 +99,15 @@ def test_each_leg_layer_against_oracle(C):
 @pytest.mark.parametrize("C", [1, 4, 5])
 def test_leg_against_oracle_and_golden(engines, fixture_images, nn_golden, C):
     imgs = fixture_images(C)
-    fv = engines[C].leg(torch.from_numpy(imgs).cuda()).cpu().numpy()
     ref = O.leg_forward(imgs, S.make_test_weights(C, seed=0), CFG, np.float64).reshape(2, 360, 128)
+    assert engines[C].leg_precision == "bf16x3"          # the default arithmetic
+    fv_default = engines[C].leg(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    assert _rel(fv_default, ref) < 5e-5 and _rel(fv_default, nn_golden["fv_c%d" % C]) < 5e-5
+    engines[C].set_leg_precision("f32")
+    try:
+        fv = engines[C].leg(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    finally:
+        engines[C].set_leg_precision("bf16x3")
     assert fv.shape == (2, 360, 128)
     assert _rel(fv, ref) < 2e-5
     assert _rel(fv, nn_golden["fv_c%d" % C]) < 2e-5
@@ -112,11 +123,8 @@ def test_leg_bf16x3_mode(engines, fixture_images, C):
     imgs = np.concatenate([fixture_images(C), S.candidate_images(4, C, seed=9)[2:]])
     w = S.make_test_weights(C, seed=0)
     e = engines[C]
-    e.set_leg_precision("bf16x3")
-    try:
-        fv = e.leg(torch.from_numpy(imgs).cuda())
-    finally:
-        e.set_leg_precision("f32")
+    assert e.leg_precision == "bf16x3"
+    fv = e.leg(torch.from_numpy(imgs).cuda())
     ref = O.leg_forward(imgs, w, CFG, np.float64)
     err = _rel(fv.cpu().numpy(), ref.reshape(-1, 360, 128))
     assert err < 5e-5, "bf16x3 leg rel err %.3g" % err
@@ -354,7 +362,7 @@ def test_infer_class_end_to_end(tmp_path, fixture_npz):
         inf.infer_one("a.txt", "b.bin")
 
     fv = inf.create_feature_volumes(["000000", "000003"])
-    assert fv.shape == (2, 1, 360, 128) and _rel(fv[1, 0], ref_fv[3, 0]) < 2e-5
+    assert fv.shape == (2, 1, 360, 128) and _rel(fv[1, 0], ref_fv[3, 0]) < 5e-5
 
     # infer_multiple: frames fed in order; l = reference frame, r = current frame
     assert inf.infer_multiple(0, []) is None
@@ -482,7 +490,7 @@ def test_infer_with_intensity_channel_and_missing_files(tmp_path, fixture_npz):
     assert inf.no_input_channels == 5 and cfg["model"]["inputShape"] == [64, 900, 5]
     fv = inf.create_feature_volumes(["000000", "000001"])       # batch_size 1 -> two leg launches
     ref = O.leg_forward(np.stack(imgs), w, CFG, np.float64)
-    assert _rel(fv, ref) < 2e-5
+    assert _rel(fv, ref) < 5e-5
     ov, yaw = inf.infer_one("a/000000.bin", "b/000001.bin")
     o_ov, o_yaw, _, _ = O.heads_forward(ref[[1]], ref[[0]], w)
     assert abs(ov[0] - o_ov[0]) < 1e-4 and yaw[0] == o_yaw[0]
