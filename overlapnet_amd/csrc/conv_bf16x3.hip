@@ -6,6 +6,8 @@
 // The K loop advances 32 at a time (one v_mfma_f32_16x16x32_bf16 step).  A-tile values are split into hi/lo
 // bf16 ONCE when they are staged into LDS (8 values per thread per chunk, amortised over all Cout columns);
 // weights are split and laid out in fragment order when the layer is registered.
+#include <stdlib.h>
+
 #include "ovn_internal.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -222,6 +224,109 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kerne
   }
 }
 
+// Split-K variant for launches with few output rows (a single scan's leg: M = 360..2490 rows against K up to 2304).
+// The tiled kernel above then runs a handful of workgroups through 36-72 serial K chunks, each a
+// load -> split -> LDS -> barrier -> MFMA round trip (~1 us): latency bound.  Here a workgroup owns 16 output rows x all
+// NT*16 output channels and its NS waves each take every NS-th K chunk: operands go global -> registers -> MFMA with
+// a one-chunk register prefetch, no LDS and no barrier in the loop; the NS partial tiles are summed through LDS in
+// a fixed order at the end (deterministic).  Needs Cin % 8 == 0 (a lane's 8 consecutive k are 8 consecutive channels).
+template <int NT, int NS>
+__global__ __launch_bounds__(64 * NS) void conv_splitk_bf16x3_kernel(ConvArgsB a) {
+  constexpr int N = NT * 16;
+  __shared__ float red[NS][16][N];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const long long m0 = (long long)blockIdx.x * 16;
+  long long m = m0 + lrow;
+  if (m >= a.M) m = a.M - 1;
+  const int ow = (int)(m % a.OW);
+  const long long t2 = m / a.OW;
+  const int oh = (int)(t2 % a.OH);
+  const long long nb = t2 / a.OH;
+  const float* arow = a.in + ((nb * a.H + (long long)oh * a.SH) * a.W + (long long)ow * a.SW) * a.Cin;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  f32x4 av[2][2];
+  bf16x8 bv[2][NT][2];
+  auto load = [&](int kc, int buf) {
+    const int k = kc * KC + 8 * g;
+    av[buf][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    av[buf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (k < a.K) {
+      const int kh = k / a.KWC;
+      const int x = k - kh * a.KWC;
+      const float* p = arow + (long long)kh * a.rowstride + x;
+      av[buf][0] = *reinterpret_cast<const f32x4*>(p);
+      av[buf][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    const __bf16* wsrc = a.wp + (long long)kc * NT * 1024 + lane * 8;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      bv[buf][j][0] = *reinterpret_cast<const bf16x8*>(wsrc + j * 1024);
+      bv[buf][j][1] = *reinterpret_cast<const bf16x8*>(wsrc + j * 1024 + 512);
+    }
+  };
+  auto compute = [&](int buf) {
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    split_pair_rne(av[buf][0][0], av[buf][0][1], h0, l0);
+    split_pair_rne(av[buf][0][2], av[buf][0][3], h1, l1);
+    split_pair_rne(av[buf][1][0], av[buf][1][1], h2, l2);
+    split_pair_rne(av[buf][1][2], av[buf][1][3], h3, l3);
+    const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
+    const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv[buf][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bv[buf][j][0], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv[buf][j][1], acc[j], 0, 0, 0);
+  };
+
+  // chunks wave, wave + NS, ... ; two per iteration so that the register buffers are addressed statically
+  int kc = wave;
+  if (kc < a.nkc) load(kc, 0);
+  while (kc < a.nkc) {
+    if (kc + NS < a.nkc) load(kc + NS, 1);
+    compute(0);
+    kc += NS;
+    if (kc >= a.nkc) break;
+    if (kc + NS < a.nkc) load(kc + NS, 0);
+    compute(1);
+    kc += NS;
+  }
+
+  // C/D layout: lane holds column lrow of n-tile j, rows 4g..4g+3
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][4 * g + r][16 * j + lrow] = acc[j][r];
+  __syncthreads();
+  for (int e = tid; e < 16 * N; e += 64 * NS) {
+    const int row = e / N;
+    const int n = e - row * N;
+    float v = red[0][row][n];
+#pragma unroll
+    for (int w = 1; w < NS; ++w) v += red[w][row][n];
+    v += a.bias[n];
+    if (a.relu) v = fmaxf(v, 0.0f);
+    if (m0 + row < a.M) a.out[(m0 + row) * a.Cout + n] = v;
+  }
+}
+
+template <int NT, int NS>
+int launch_conv_splitk(const ConvArgsB& a, hipStream_t stream) {
+  hipLaunchKernelGGL((conv_splitk_bf16x3_kernel<NT, NS>), dim3((unsigned)((a.M + 15) / 16)), dim3(64 * NS), 0, stream, a);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
 template <int WM, int WN, int WAVES_M, int WAVES_N>
 int launch_conv_b(const ConvArgsB& a, bool vec4, hipStream_t stream) {
   constexpr int BM = 16 * WM * WAVES_M;
@@ -252,7 +357,7 @@ int ovn_conv_prepare_bf16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_
 }
 
 int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh_out,
-                            int* ow_out, hipStream_t stream) {
+                            int* ow_out, hipStream_t stream, bool few_rows) {
   OVN_REQUIRE(L.wp_bf != nullptr && L.bias != nullptr, OVN_ERR_STATE, "layer %s has no bf16x3 weights", L.name.c_str());
   OVN_REQUIRE(h >= L.kh && w >= L.kw, OVN_ERR_ARG, "layer %s: input %dx%d smaller than kernel", L.name.c_str(), h, w);
   ConvArgsB a;
@@ -278,6 +383,16 @@ int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int 
   if (ow_out) *ow_out = a.OW;
   if (a.M == 0) return OVN_OK;
   const bool vec4 = (L.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+  // few output rows (single-scan leg): split K across the waves of 16-row workgroups instead of tiling M
+  static const int splitk = getenv("OVN_CONV_SPLITK") ? atoi(getenv("OVN_CONV_SPLITK")) : 1;
+  if (splitk && few_rows && vec4 && L.cin % 8 == 0 && a.M <= 4096 && a.nkc >= 8) {
+    switch (L.cout) {
+      case 32: return launch_conv_splitk<2, 8>(a, stream);
+      case 64: return launch_conv_splitk<4, 8>(a, stream);
+      case 128: return launch_conv_splitk<8, 8>(a, stream);
+      default: break;
+    }
+  }
   switch (L.cout) {
     case 16: return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);
     case 32: return launch_conv_b<2, 2, 4, 1>(a, vec4, stream);

@@ -223,7 +223,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
-                                  : ovn_conv_forward_bf16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream);
+                                  : ovn_conv_forward_bf16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream, n <= 8);
       }
       if (rc) return rc;
       cur = dst;
@@ -427,7 +427,8 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
   OVN_HIP_CHECK(hipSetDevice(ctx->device));
   int oh = 0, ow = 0;
   return (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream)
-                              : ovn_conv_forward_bf16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
+                              : ovn_conv_forward_bf16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream,
+                                                        nb <= 8);
 }
 
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream) {

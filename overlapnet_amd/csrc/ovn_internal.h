@@ -125,8 +125,10 @@ int ovn_conv_forward(const OvnConvLayer& L, const float* in, int nb, int h, int 
 
 // conv_bf16x3.hip
 int ovn_conv_prepare_bf16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream);
+// few_rows: the whole call (not just this slice) is a handful of scans -> the split-K kernels may be used; decided by
+// the caller so that every scan of one call takes the same code path (bit-identical results per batch position)
 int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh,
-                            int* ow, hipStream_t stream);
+                            int* ow, hipStream_t stream, bool few_rows = false);
 
 // delta_head.hip
 int ovn_delta_prepare_w1(const float* c1_kernel_dev, float** w1p_out, hipStream_t stream);
