@@ -143,10 +143,6 @@ int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_
 int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                  const int32_t* ridx, int n, float* o2, hipStream_t stream);
 
-// delta_head_bf16x3_j2.hip (default schedule: two column groups per W1 pass)
-int ovn_delta_c12_bf16x3_j2_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                    const int32_t* ridx, int n, float* o2, hipStream_t stream);
-
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
                      int n, int32_t* yaw, float* corr, hipStream_t stream);

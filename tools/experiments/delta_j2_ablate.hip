@@ -1,4 +1,4 @@
-// Timing ablations of the shipped two-group Delta kernel, generated from overlapnet_amd/csrc/delta_head_bf16x3_j2.hip by
+// Timing ablations of the shipped two-group Delta kernel, generated from overlapnet_amd/csrc/delta_head_bf16x3.hip by
 // tools/experiments/make_delta_j2_ablate.py (results are WRONG by construction, only the timings mean anything).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -66,6 +66,49 @@ __device__ __forceinline__ void make_a(const f32x4& l0, const f32x4& l1, const f
 __device__ __forceinline__ void split_bf16(float x, __bf16& hi, __bf16& lo) {
   hi = (__bf16)x;
   lo = (__bf16)(x - (float)hi);
+}
+
+// W1p[u = s*15 + dj][nt(4)][hl(2)][lane(64)][e(8)]: W1[dj][c = 32*(lane>>4) + 8*s + e][o = 16*nt + (lane&15)]
+__global__ void delta_prep_w1_bf16_kernel(const float* __restrict__ w1, __bf16* __restrict__ w1p) {
+  const int total = S * 4 * 4 * 64 * 8;  // (hi, lo) pairs
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 3;
+    const int u = idx >> 11;  // 0..59
+    const int s = u / S;
+    const int dj = u - s * S;
+    const int c = 32 * (lane >> 4) + 8 * s + e;
+    const int o = 16 * nt + (lane & 15);
+    __bf16 hi, lo;
+    split_bf16(w1[(dj * FC + c) * O1 + o], hi, lo);
+    const size_t base = (((size_t)u * 4 + nt) * 2) * 512 + lane * 8 + e;
+    w1p[base] = hi;
+    w1p[base + 512] = lo;
+  }
+}
+
+// W2p[ks(30)][nt(8)][hl(2)][lane(64)][e(8)]: W2[k(k')][p = 16*nt + (lane&15)], k' = 32*ks + 8*(lane>>4) + e.
+// GEMM2 walks its K axis in the order k' = di*64 + 4*(o & 15) + (o >> 4) instead of k = di*64 + o: the four c_conv1
+// n-tiles a lane holds after GEMM1 (o = lrow, 16+lrow, 32+lrow, 48+lrow) are then adjacent in the o1 image, so the
+// epilogue stores 8 bytes per (row, hi/lo) instead of four 2-byte pieces.  Any K order works as long as A and B agree.
+__global__ void delta_prep_w2_bf16_kernel(const float* __restrict__ w2, __bf16* __restrict__ w2p) {
+  const int total = (K2 / 32) * 8 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 7;
+    const int ks = idx >> 12;
+    const int kp = 32 * ks + 8 * (lane >> 4) + e;
+    const int m = kp & 63;
+    const int k = (kp & ~63) + 16 * (m & 3) + (m >> 2);
+    const int p = 16 * nt + (lane & 15);
+    __bf16 hi, lo;
+    split_bf16(w2[k * O2 + p], hi, lo);
+    const size_t base = (((size_t)ks * 8 + nt) * 2) * 512 + lane * 8 + e;
+    w2p[base] = hi;
+    w2p[base + 512] = lo;
+  }
 }
 
 template <int T, int NW, bool DMA, int ABL>

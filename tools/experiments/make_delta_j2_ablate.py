@@ -7,7 +7,7 @@ ABL bits: 1 no W1 staging, 2 no slice barriers, 8 no B LDS reads (constant fragm
 compiler hoists the split out of the step loop.)"""
 import os
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-src = open(os.path.join(root, "overlapnet_amd/csrc/delta_head_bf16x3_j2.hip")).read()
+src = open(os.path.join(root, "overlapnet_amd/csrc/delta_head_bf16x3.hip")).read()
 
 
 def rep(s, old, new, count=1):
@@ -130,7 +130,7 @@ int main() {
   return 0;
 }
 '''
-out = ("// Timing ablations of the shipped two-group Delta kernel, generated from overlapnet_amd/csrc/delta_head_bf16x3_j2.hip by\n"
+out = ("// Timing ablations of the shipped two-group Delta kernel, generated from overlapnet_amd/csrc/delta_head_bf16x3.hip by\n"
        "// tools/experiments/make_delta_j2_ablate.py (results are WRONG by construction, only the timings mean anything).\n"
        "#include <hip/hip_runtime.h>\n#include <stdint.h>\n#define OVN_FEAT_W 360\n#define OVN_FEAT_C 128\n#define OVN_S 15\n"
        "#define OVN_G 24\n#define OVN_C1_OUT 64\n#define OVN_C2_OUT 128\n#define OVN_FEAT_ELEMS (360 * 128)\n"
