@@ -99,3 +99,50 @@ def test_error_statistics(tmp_path):
     st = E.error_statistics([0.85, 0.3, 0.7], ov, [0, 0, -178], E.yaw_bin_to_degrees(yb))
     assert st["n"] == 3 and abs(st["overlap_mae"] - (0.05 + 0.1 + 0.1) / 3) < 1e-12 and abs(st["overlap_max"] - 0.1) < 1e-12
     assert st["yaw_n"] == 2 and st["yaw_max_err_deg"] == 7 and abs(st["yaw_mean_err_deg"] - 3.5) < 1e-12
+
+
+def test_pair_reader_both_layouts_and_test_run(tmp_path):
+    """load_pairs against files written the way demo4 writes them (demo4_gen_gt_files.py:97-109) and in the old
+    single-array layout, cross-checked with the reference's own reader when the reference tree is present."""
+    import os
+    import sys
+    rng = np.random.default_rng(3)
+    n = 7
+    arr = np.zeros((n, 4))
+    arr[:, 0] = 5
+    arr[:, 1] = rng.permutation(n)
+    arr[:, 2] = rng.random(n)
+    arr[:, 3] = rng.integers(0, 360, n)
+    seq = np.empty((n, 2), dtype=object)
+    seq[:] = "07"
+    new = str(tmp_path / "gt.npz")
+    old = str(tmp_path / "old.npz")
+    np.savez_compressed(new, overlaps=arr, seq=seq)
+    np.savez(old, arr)
+    f1, f2, d1, d2, ov, ori = E.load_pairs([new, old])
+    assert f1[:n] == ["000005"] * n and f2[:n] == ["%06d" % v for v in arr[:, 1]] and d1[:n] == ["07"] * n
+    assert d1[n:] == [""] * n and np.array_equal(ov, np.tile(arr[:, 2], 2)) and np.array_equal(ori, np.tile(arr[:, 3], 2))
+    ref_dir = "/root/reference/src/two_heads"
+    if os.path.isdir(ref_dir):                      # same answer as the reference's reader
+        sys.path.insert(0, ref_dir)
+        try:
+            from overlap_orientation_npz_file2string_string_nparray import overlap_orientation_npz_file2string_string_nparray as ref
+        finally:
+            sys.path.pop(0)
+        r = ref([new, old], shuffle=False)
+        assert list(r[0]) == f1 and list(r[1]) == f2 and list(r[2]) == d1 and list(r[3]) == d2
+        assert np.array_equal(r[4], ov) and np.array_equal(r[5], ori)
+
+    class FakeInfer:            # records the pair roles run_test asks for
+        def infer_multiple_vs_multiple(self, names, first, second):
+            self.names, self.first, self.second = list(names), list(first), list(second)
+            k = len(first)
+            return np.linspace(0.1, 0.9, k).astype(np.float32), (180 - np.arange(k) * 3).astype(np.int64)
+
+    inf = FakeInfer()
+    st = E.run_test(inf, [new], no_test_pairs=5, out_dir=str(tmp_path / "res"))
+    assert inf.names == sorted(set(f1[:5]) | set(f2[:5]))
+    assert [inf.names[i] for i in inf.second] == f1[:5] and [inf.names[i] for i in inf.first] == f2[:5]   # l = imgf1, r = imgf2
+    m = np.load(str(tmp_path / "res" / "validation_results.npz"))["arr_0"]
+    assert m.shape == (5, 4) and np.array_equal(m[:, 3], np.arange(5) * 3) and np.allclose(m[:, 2], np.linspace(0.1, 0.9, 5))
+    assert st["n"] == 5 and abs(st["overlap_mae"] - np.mean(np.abs(np.linspace(0.1, 0.9, 5) - arr[:5, 2]))) < 1e-6
