@@ -133,13 +133,26 @@ int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_de
 int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,
                 float* normal_dev, void* stream);
 
+/* Ground-truth overlap labels (src/utils/com_overlap_yaw.py:28-46), the producer of the training / evaluation targets.
+ * ovn_gt_range_images: range images (n, H, W) f32 (-1 = empty) of n scans moved by p' = inv_cur_pose . (ref_pose[s] . p)
+ *   and range-projected in FLOAT64 as `range_projection` does for load_vertex's float64 points (utils.py:59-134,217-230).
+ *   points/offsets as in ovn_project; ref_poses_dev (n,4,4) f64 row-major or NULL (identity); inv_cur_pose_dev (4,4) f64 or
+ *   NULL (identity) -- with both NULL this is the current frame's own range image (com_overlap_yaw.py:30-31).
+ * ovn_gt_overlap_counts: counts_dev[s] = #{ref_range[s] > 0 and |ref_range[s] - cur_range| < 1} for s < n, and
+ *   counts_dev[n] = #{cur_range > 0} (`valid_num`, :32-33): overlap[s] = counts[s] / counts[n] (:42-45). */
+int ovn_gt_range_images(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_dev, int n_scans,
+                        int64_t max_points_per_scan, const double* ref_poses_dev, const double* inv_cur_pose_dev, int proj_h,
+                        int proj_w, double fov_up_deg, double fov_down_deg, double max_range, float* range_dev, void* stream);
+int ovn_gt_overlap_counts(ovn_ctx* ctx, const float* ref_ranges_dev, const float* cur_range_dev, int n_scans, int proj_h,
+                          int proj_w, int32_t* counts_dev, void* stream);
+
 /* Arithmetic of the Delta head's c_conv1/c_conv2 contractions (storage and accumulation are fp32 either way):
  *   0 = fp32 matrix cores (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 FMA chain),
  *   1 = 3-term bf16 split on the bf16 matrix cores (x = hi + lo, a*w ~ ah*wh + al*wh + ah*wl; ~2^-17 per product)
  *       -- the default; both modes are held to |d overlap| <= 1e-4 against the fp64 oracle by the parity tests. */
 int ovn_set_head_precision(ovn_ctx* ctx, int mode);
 
-/* Arithmetic of the leg convolutions, same two modes as ovn_set_head_precision (default 0 = fp32 matrix cores). */
+/* Arithmetic of the leg convolutions, same two modes as ovn_set_head_precision (default 1). */
 int ovn_set_leg_precision(ovn_ctx* ctx, int mode);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream, for bench.py's roofline line.

@@ -354,3 +354,81 @@ def infer_pairs(images_nhwc: np.ndarray, pairs: np.ndarray, weights, model_cfg=N
         o, y, g, c = heads_forward(fv[p[:, 0]], fv[p[:, 1]], weights, s, dtype)
         ov.append(o); yw.append(y); lg.append(g); cr.append(c)
     return (np.concatenate(ov), np.concatenate(yw), np.concatenate(lg), np.concatenate(cr), fv)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ground-truth overlap / yaw -- PINNED by tests/golden/gt_overlap_yaw.npz, which was produced by
+# running the reference's own src/utils/com_overlap_yaw.py in the build container (tests/golden/make_gt_golden.py)
+# ------------------------------------------------------------------------------------------------------------
+def range_image_f64(points_xyz1: np.ndarray, fov_up: float = 3.0, fov_down: float = -25.0, proj_H: int = 64,
+                    proj_W: int = 900, max_range: float = 50.0) -> np.ndarray:
+    """The range image `range_projection` (utils.py:59-134) yields for FLOAT64 homogeneous points, which is what
+    com_overlap_yaw.py:30,38-42 feeds it (`load_vertex`, utils.py:217-230, builds float64 arrays): all arithmetic in
+    float64, the winning depth rounded to float32 when stored (`proj_range` is a float32 image, utils.py:120-121).
+    Nearest point wins = per-pixel minimum of the depth."""
+    p = np.asarray(points_xyz1, F64)
+    up = fov_up / 180.0 * np.pi
+    down = fov_down / 180.0 * np.pi
+    fov = abs(down) + abs(up)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    depth = np.sqrt((x * x + y * y) + z * z)
+    keep = (depth > 0) & (depth < max_range)
+    x, y, z, depth = x[keep], y[keep], z[keep], depth[keep]
+    yaw = -np.arctan2(y, x)
+    pitch = np.arcsin(z / depth)
+    px = 0.5 * (yaw / np.pi + 1.0)
+    py = 1.0 - (pitch + abs(down)) / fov
+    px = px * proj_W
+    py = py * proj_H
+    px = np.maximum(0, np.minimum(proj_W - 1, np.floor(px))).astype(np.int64)
+    py = np.maximum(0, np.minimum(proj_H - 1, np.floor(py))).astype(np.int64)
+    best = np.full(proj_H * proj_W, np.inf, F64)
+    np.minimum.at(best, py * proj_W + px, depth)
+    out = np.where(np.isfinite(best), best, -1.0).astype(F32)
+    return out.reshape(proj_H, proj_W)
+
+
+def yaw_bin_from_poses(current_pose: np.ndarray, reference_pose: np.ndarray, leg_output_width: int = 360) -> int:
+    """com_overlap_yaw.py:49-55 with euler_angles_from_rotation_matrix (utils.py:186-214), Python operator
+    precedence included: `int(-(yaw / pi) * W // 2 + W // 2)` floors (-(yaw/pi) * W) / 2 BEFORE adding W // 2."""
+    import math
+    R = np.linalg.inv(current_pose).dot(reference_pose)[:3, :3]
+
+    def isclose(a, b, rtol=1.e-5, atol=1.e-8):
+        return abs(a - b) <= atol + rtol * abs(b)
+
+    phi = 0.0
+    if isclose(R[2, 0], -1.0) or isclose(R[2, 0], 1.0):
+        pass  # gimbal lock: the reference leaves phi (yaw) at 0
+    else:
+        theta = -math.asin(R[2, 0])
+        cos_theta = math.cos(theta)
+        phi = math.atan2(R[1, 0] / cos_theta, R[0, 0] / cos_theta)
+    return int(-(phi / np.pi) * leg_output_width // 2 + leg_output_width // 2)
+
+
+def com_overlap_yaw(scans_xyz: Sequence[np.ndarray], poses: np.ndarray, frame_idx: int, leg_output_width: int = 360
+                    ) -> np.ndarray:
+    """Ground-truth mapping of one frame against all scans (com_overlap_yaw.py:10-68): rows
+    [frame_idx, reference_idx, overlap, yaw_bin].  `scans_xyz[i]` = (N_i, >=3) points of scan i."""
+    def homog(a):
+        a = np.asarray(a)
+        h = np.ones((a.shape[0], 4), F64)
+        h[:, :3] = a[:, :3]
+        return h
+
+    cur = range_image_f64(homog(scans_xyz[frame_idx]))
+    valid_num = int(np.count_nonzero(cur > 0))
+    cur_pose = poses[frame_idx]
+    n = len(scans_xyz)
+    out = np.zeros((n, 4))
+    out[:, 0] = frame_idx
+    out[:, 1] = np.arange(n)
+    inv_cur = np.linalg.inv(cur_pose)
+    for r in range(n):
+        world = poses[r].dot(homog(scans_xyz[r]).T).T
+        ref = range_image_f64(inv_cur.dot(world.T).T)
+        sel = ref > 0
+        out[r, 2] = np.count_nonzero(np.abs(ref[sel] - cur[sel]) < 1) / valid_num
+        out[r, 3] = yaw_bin_from_poses(cur_pose, poses[r], leg_output_width)
+    return out

@@ -38,6 +38,9 @@ SIGNATURES = {
     "ovn_project": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                               C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ovn_normals": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "ovn_gt_range_images": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_double, _vp, _vp]),
+    "ovn_gt_overlap_counts": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ovn_set_head_precision": (C.c_int, [_vp, C.c_int]),
     "ovn_set_leg_precision": (C.c_int, [_vp, C.c_int]),
     "ovn_profile_begin": (C.c_int, [_vp]),

@@ -369,6 +369,28 @@ int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, i
   return ovn_normals_forward(range_dev, vertex_dev, n_scans, proj_h, proj_w, normal_dev, (hipStream_t)stream);
 }
 
+int ovn_gt_range_images(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_dev, int n_scans,
+                        int64_t max_points_per_scan, const double* ref_poses_dev, const double* inv_cur_pose_dev, int proj_h,
+                        int proj_w, double fov_up_deg, double fov_down_deg, double max_range, float* range_dev, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_gt_range_images: ctx is NULL");
+  OVN_REQUIRE(n_scans >= 0 && proj_h > 0 && proj_w > 0 && max_points_per_scan >= 0, OVN_ERR_ARG, "ovn_gt_range_images: bad sizes");
+  if (n_scans == 0) return OVN_OK;
+  OVN_REQUIRE(offsets_dev && range_dev && (points_dev || max_points_per_scan == 0), OVN_ERR_ARG, "ovn_gt_range_images: NULL buffer");
+  OVN_REQUIRE(n_scans <= 65535, OVN_ERR_ARG, "ovn_gt_range_images: at most 65535 scans per call");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return ovn_gt_range_forward(points_dev, offsets_dev, n_scans, max_points_per_scan, ref_poses_dev, inv_cur_pose_dev, proj_h,
+                              proj_w, fov_up_deg, fov_down_deg, max_range, range_dev, (hipStream_t)stream);
+}
+
+int ovn_gt_overlap_counts(ovn_ctx* ctx, const float* ref_ranges_dev, const float* cur_range_dev, int n_scans, int proj_h,
+                          int proj_w, int32_t* counts_dev, void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_gt_overlap_counts: ctx is NULL");
+  OVN_REQUIRE(n_scans >= 0 && proj_h > 0 && proj_w > 0, OVN_ERR_ARG, "ovn_gt_overlap_counts: bad sizes");
+  OVN_REQUIRE(cur_range_dev && counts_dev && (ref_ranges_dev || n_scans == 0), OVN_ERR_ARG, "ovn_gt_overlap_counts: NULL buffer");
+  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  return ovn_gt_count_forward(ref_ranges_dev, cur_range_dev, n_scans, proj_h * proj_w, counts_dev, (hipStream_t)stream);
+}
+
 int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
   OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);

@@ -150,6 +150,11 @@ int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* fea
 // corr_spectral.hip
 int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
+// overlap_gt.hip
+int ovn_gt_range_forward(const float* points, const int64_t* offsets, int n_scans, long long max_points, const double* ref_poses,
+                         const double* inv_cur_pose, int H, int W, double fov_up_deg, double fov_down_deg, double max_range,
+                         float* range_out, hipStream_t stream);
+int ovn_gt_count_forward(const float* ref_ranges, const float* cur_range, int n, int npix, int32_t* counts, hipStream_t stream);
 int ovn_best_match_forward(const float* overlap, const int32_t* yaw, const int32_t* ids, int n, float threshold,
                            int index_offset, int32_t* out, hipStream_t stream);
 int ovn_corr_spectral_forward(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,

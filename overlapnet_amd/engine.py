@@ -218,6 +218,43 @@ class OvnEngine:
                                                        _ptr(yaw), _ptr(corr), self._stream()), "ovn_corr_head_spectral")
         return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
 
+    # -- ground-truth labels -------------------------------------------------------------------------
+    def gt_range_images(self, points: torch.Tensor, offsets: torch.Tensor, max_points: int,
+                        ref_poses: Optional[torch.Tensor] = None, inv_cur_pose: Optional[torch.Tensor] = None,
+                        proj_h: int = 64, proj_w: int = 900, fov_up: float = 3.0, fov_down: float = -25.0,
+                        max_range: float = 50.0) -> torch.Tensor:
+        """Float64 range projection of scans moved by inv_cur_pose . ref_poses[s] (com_overlap_yaw.py:37-40):
+        (n, H, W) f32 device tensor, -1 = empty.  points (total,4) f32, offsets (n+1) i64, poses float64 device tensors."""
+        n = int(offsets.numel()) - 1
+        for t, what, dt in ((points, "points", torch.float32), (offsets, "offsets", torch.int64),
+                            (ref_poses, "ref_poses", torch.float64), (inv_cur_pose, "inv_cur_pose", torch.float64)):
+            if t is not None and (t.device != self.device or t.dtype != dt or not t.is_contiguous()):
+                raise _lib.OvnError("%s must be a contiguous %s tensor on %s" % (what, dt, self.device))
+        if ref_poses is not None and ref_poses.numel() != 16 * n:
+            raise _lib.OvnError("ref_poses must hold %d 4x4 matrices" % n)
+        if inv_cur_pose is not None and inv_cur_pose.numel() != 16:
+            raise _lib.OvnError("inv_cur_pose must be one 4x4 matrix")
+        out = torch.empty((n, proj_h, proj_w), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_gt_range_images(self._h, _ptr(points), _ptr(offsets), n, int(max_points), _ptr(ref_poses),
+                                                    _ptr(inv_cur_pose), proj_h, proj_w, float(fov_up), float(fov_down),
+                                                    float(max_range), _ptr(out), self._stream()), "ovn_gt_range_images")
+        return out
+
+    def gt_overlap_counts(self, ref_ranges: torch.Tensor, cur_range: torch.Tensor) -> torch.Tensor:
+        """(n+1) int32: per reference scan the pixels with |ref - cur| < 1 (ref > 0); last entry = #{cur > 0}."""
+        n, h, w = ref_ranges.shape
+        for t, what in ((ref_ranges, "ref_ranges"), (cur_range, "cur_range")):
+            if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise _lib.OvnError("%s must be a contiguous float32 tensor on %s" % (what, self.device))
+        if tuple(cur_range.shape[-2:]) != (h, w) or cur_range.numel() != h * w:
+            raise _lib.OvnError("cur_range must be one %dx%d image" % (h, w))
+        counts = torch.empty(n + 1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_gt_overlap_counts(self._h, _ptr(ref_ranges), _ptr(cur_range), n, h, w, _ptr(counts),
+                                                      self._stream()), "ovn_gt_overlap_counts")
+        return counts
+
     # -- loop-closure decision -----------------------------------------------------------------------
     def best_match(self, overlap: torch.Tensor, yaw: Optional[torch.Tensor] = None, threshold: float = 0.3,
                    ids: Optional[torch.Tensor] = None, index_offset: int = 0) -> torch.Tensor:

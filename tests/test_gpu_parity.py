@@ -548,3 +548,42 @@ def test_full_size_sweep_properties(engines):
                                         np.repeat(q.reshape(1, 1, 360, 128).astype(np.float64), 3, axis=0),
                                         S.make_test_weights(4, seed=0))
     assert np.max(np.abs(r["overlap"].cpu().numpy()[idx] - o_ov)) <= 1e-4 and np.array_equal(yaw[idx], o_yaw)
+
+
+def test_ground_truth_overlap_yaw_against_reference_golden(fixture_npz):
+    """csrc/overlap_gt.hip + ground_truth.py against the mapping the reference's own com_overlap_yaw.py produced
+    (tests/golden/make_gt_golden.py): yaw bins exact, overlaps equal up to a few pixels of 45 k (float64 atan2/asin
+    of the device library vs glibc can move a point that sits on a pixel edge)."""
+    from overlapnet_amd.ground_truth import OverlapGroundTruth, com_overlap_yaw
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gt_overlap_yaw.npz"))
+    scans = [fixture_npz["points_%d" % s] for s in z["scan_of"]]
+    gt = OverlapGroundTruth(scans, z["poses"])
+    worst = 0.0
+    for f in (0, 4, 7, 11):
+        m = gt.mapping(f)
+        ref = z["mapping_%d" % f]
+        assert np.array_equal(m[:, [0, 1, 3]], ref[:, [0, 1, 3]])
+        d = np.abs(m[:, 2] - ref[:, 2])
+        worst = max(worst, float(d.max()))
+        assert d.max() <= 3.0 / 40000, "frame %d: overlaps differ by %.3g" % (f, d.max())
+        assert m[f, 2] == 1.0                                   # a scan overlaps itself completely
+    print("ground-truth overlap: max |gpu - reference| = %.3g" % worst)
+    # the range image the kernel builds for the untransformed frame equals the float64 oracle's
+    e = gt.engine
+    pts = torch.from_numpy(np.ascontiguousarray(scans[0], np.float32)).cuda()
+    img = e.gt_range_images(pts, torch.tensor([0, pts.shape[0]], dtype=torch.int64).cuda(), pts.shape[0]).cpu().numpy()[0]
+    h = np.ones((scans[0].shape[0], 4))
+    h[:, :3] = scans[0][:, :3]
+    ref_img = O.range_image_f64(h)
+    assert np.count_nonzero(img != ref_img) <= 4
+    # drop-in function on .bin files, ragged / empty inputs
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        paths = []
+        for i in range(3):
+            pth = os.path.join(tmp, "%06d.bin" % i)
+            (scans[i][: 1000 * i] if i else scans[0]).astype(np.float32).tofile(pth)     # scan 1: 1000 points, scan 2: 2000
+            paths.append(pth)
+        m = com_overlap_yaw(paths, z["poses"][:3], 0)
+        want = O.com_overlap_yaw([scans[0], scans[1][:1000], scans[2][:2000]], z["poses"][:3], 0)
+        assert np.array_equal(m[:, 3], want[:, 3]) and np.max(np.abs(m[:, 2] - want[:, 2])) <= 3.0 / 40000
