@@ -587,3 +587,40 @@ def test_ground_truth_overlap_yaw_against_reference_golden(fixture_npz):
         m = com_overlap_yaw(paths, z["poses"][:3], 0)
         want = O.com_overlap_yaw([scans[0], scans[1][:1000], scans[2][:2000]], z["poses"][:3], 0)
         assert np.array_equal(m[:, 3], want[:, 3]) and np.max(np.abs(m[:, 2] - want[:, 2])) <= 3.0 / 40000
+
+
+@pytest.mark.parametrize("pca", [True, False])
+def test_infer_with_semantic_channels(tmp_path, fixture_npz, pca):
+    """`use_class_probabilities[_pca]` inputs (ImagePairOverlapOrientationSequence.py:165-195): channel order
+    depth -> normals -> probabilities (20, or 3 after PCA) -> intensity; C = 25 / 8 with every cue on."""
+    from overlapnet_amd.infer import Infer
+    k = 3 if pca else 20
+    sub = "probability_pca" if pca else "probability"
+    seq = tmp_path / "data" / "07"
+    for d in ("depth", "normal", "intensity", sub):
+        os.makedirs(seq / d)
+    rng = np.random.default_rng(11)
+    imgs = []
+    for i in range(2):
+        prob = rng.random((64, 900, k)).astype(np.float32)
+        prob /= prob.sum(axis=2, keepdims=True)
+        np.save(seq / "depth" / ("%06d.npy" % i), fixture_npz["range_%d" % i])
+        np.save(seq / "normal" / ("%06d.npy" % i), fixture_npz["normal_%d" % i])
+        np.save(seq / "intensity" / ("%06d.npy" % i), fixture_npz["intensity_%d" % i])
+        np.save(seq / sub / ("%06d.npy" % i), prob)
+        imgs.append(np.concatenate([fixture_npz["range_%d" % i][..., None], fixture_npz["normal_%d" % i], prob,
+                                    fixture_npz["intensity_%d" % i][..., None]], axis=2).astype(np.float32))
+    C = 1 + 3 + k + 1
+    cfg = {"model": dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900]), "infer_seqs": "07",
+           "data_root_folder": str(tmp_path / "data"), "use_depth": True, "use_normals": True,
+           "use_class_probabilities": True, "use_class_probabilities_pca": pca, "use_intensity": True,
+           "batch_size": 16, "pretrained_weightsfilename": ""}
+    w = W.synthetic_weights(C, CFG, seed=2, kernel_gain=1.3)
+    inf = Infer(cfg, weights=w)
+    assert inf.no_input_channels == C and cfg["model"]["inputShape"] == [64, 900, C]
+    fv = inf.create_feature_volumes(["000000", "000001"])
+    ref = O.leg_forward(np.stack(imgs), w, CFG, np.float64)
+    assert _rel(fv, ref) < 5e-5
+    ov, yaw = inf.infer_one("a/000000.bin", "b/000001.bin")
+    o_ov, o_yaw, _, _ = O.heads_forward(ref[[1]], ref[[0]], w)
+    assert abs(ov[0] - o_ov[0]) < 1e-4 and yaw[0] == o_yaw[0]
