@@ -108,3 +108,35 @@ def gen_normal_data(scan_folder, dst_folder, normalize=False):
 def gen_intensity_data(scan_folder, dst_folder, normalize=False):
     """ (64,900) intensity images -> dst_folder/intensity/%06d.npy (gen_intensity_data.py:10-43). """
     return _gen_data(scan_folder, dst_folder, 'intensity', 'intensity', normalize)
+
+
+def gen_semantic_data(semantic_folder, scan_folder, dst_folder, proj_H=64, proj_W=900):
+    """ (64,900,20) projected class probabilities -> dst_folder/semantic/<scan name>.npy (gen_semantic_data.py:11-57).
+        Raw inputs: per-point float32 (N,20) probability files, one per scan, in sorted order.  The correspondences are
+        the projection's `proj_idx` with max_range = inf (gen_semantic_data.py:39); like the reference, that index (taken
+        after the depth > 0 filter) addresses the unfiltered probability array. """
+    dst = os.path.join(dst_folder, 'semantic')
+    try:
+        os.stat(dst)
+        print('generating semantic data in: ', dst)
+    except OSError:
+        print('creating new semantic folder: ', dst)
+        os.mkdir(dst)
+    prob_paths = load_files(semantic_folder)
+    scan_paths = load_files(scan_folder)
+    semantics = []
+    bs = 64
+    for s in range(0, len(prob_paths), bs):
+        scans = [np.fromfile(p, dtype=np.float32).reshape((-1, 4)) for p in scan_paths[s:s + bs][:len(prob_paths) - s]]
+        idx = project_scans(scans, proj_H=proj_H, proj_W=proj_W, max_range=np.inf, want=("idx",))["idx"].cpu().numpy()
+        for k in range(idx.shape[0]):
+            probs = np.fromfile(prob_paths[s + k], dtype=np.float32).reshape((-1, 20))
+            proj_idx = idx[k]
+            proj_prob = np.full((proj_H, proj_W, 20), -1, dtype=np.float32)
+            proj_prob[proj_idx >= 0] = probs[proj_idx[proj_idx >= 0]]
+            base_name = os.path.basename(scan_paths[s + k]).replace('.bin', '')
+            dst_path = os.path.join(dst, base_name)
+            np.save(dst_path, proj_prob)
+            semantics.append(proj_prob)
+            print('finished generating semantic data at: ', dst_path)
+    return semantics

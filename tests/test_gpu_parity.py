@@ -624,3 +624,29 @@ def test_infer_with_semantic_channels(tmp_path, fixture_npz, pca):
     ov, yaw = inf.infer_one("a/000000.bin", "b/000001.bin")
     o_ov, o_yaw, _, _ = O.heads_forward(ref[[1]], ref[[0]], w)
     assert abs(ov[0] - o_ov[0]) < 1e-4 and yaw[0] == o_yaw[0]
+
+
+def test_gen_semantic_data_against_reference_golden(tmp_path, fixture_npz):
+    """preprocess.gen_semantic_data against a run of the reference's gen_semantic_data.py on the same seeded per-point
+    probabilities (tests/golden/make_semantic_golden.py): correspondences = proj_idx with max_range = inf."""
+    from overlapnet_amd import preprocess as P
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "semantic_idx.npz"))
+    os.makedirs(tmp_path / "scans")
+    os.makedirs(tmp_path / "probs")
+    os.makedirs(tmp_path / "dst")
+    probs = []
+    for i in range(2):
+        pts = fixture_npz["points_%d" % i]
+        pts.astype(np.float32).tofile(tmp_path / "scans" / ("%06d.bin" % i))
+        pr = np.random.default_rng(100 + i).random((pts.shape[0], 20)).astype(np.float32)
+        pr.tofile(tmp_path / "probs" / ("%06d.label" % i))
+        probs.append(pr)
+    sem = P.gen_semantic_data(str(tmp_path / "probs"), str(tmp_path / "scans"), str(tmp_path / "dst"))
+    for i in range(2):
+        idx = z["idx_%d" % i]
+        want = np.full((64, 900, 20), -1, np.float32)
+        want[idx >= 0] = probs[i][idx[idx >= 0]]
+        assert abs(want.astype(np.float64).sum() - float(z["sum_%d" % i])) < 1e-6       # the golden run itself
+        diff_px = np.count_nonzero(np.any(sem[i] != want, axis=2))
+        assert diff_px <= 8, "scan %d: %d pixels differ" % (i, diff_px)                 # same gate as the projection test
+        assert np.array_equal(np.load(tmp_path / "dst" / "semantic" / ("%06d.npy" % i)), sem[i])
