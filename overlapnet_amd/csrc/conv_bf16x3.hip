@@ -103,21 +103,49 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kerne
   f32x4 areg[A_SLOTS][2];
   f32x4 breg[B_PER_THREAD];
 
+  // VEC4: position of this thread's 8 k inside the kernel window, kept incrementally (chunks are visited in order, k
+  // advances by KC per chunk): ax = offset inside the kernel row, aoff = kh * rowstride.  No integer division in the loop.
+  int ax = 0, aoff = 0;
+  if (VEC4) {
+    const int k0 = 8 * (tid & 3);
+    const int kh0 = k0 / a.KWC;
+    ax = k0 - kh0 * a.KWC;
+    aoff = kh0 * a.rowstride;
+  }
+
   auto load_chunk = [&](int kc) {
+    if (VEC4) {
+      const bool wrap1 = ax + 4 >= a.KWC;  // the second group of 4 may start on the next kernel row
+      const int x1 = ax + 4 - (wrap1 ? a.KWC : 0), off1 = aoff + (wrap1 ? a.rowstride : 0);
+      const int k = kc * KC + 8 * (tid & 3);
 #pragma unroll
-    for (int r = 0; r < A_SLOTS; ++r) {
-      const int slot = tid + r * NTHREADS;
+      for (int r = 0; r < A_SLOTS; ++r) {   // NTHREADS % 4 == 0: every slot of a thread shares (slot & 3)
+        f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+        if (k < a.K) v0 = *reinterpret_cast<const f32x4*>(a.in + abase[r] + aoff + ax);
+        if (k + 4 < a.K) v1 = *reinterpret_cast<const f32x4*>(a.in + abase[r] + off1 + x1);
+        areg[r][0] = v0;
+        areg[r][1] = v1;
+      }
+      ax += KC;
+      if (a.KWC >= KC) {  // one conditional step is enough (no loop, no branch: two selects)
+        const bool wrap = ax >= a.KWC;
+        ax -= wrap ? a.KWC : 0;
+        aoff += wrap ? a.rowstride : 0;
+      } else {
+        while (ax >= a.KWC) {
+          ax -= a.KWC;
+          aoff += a.rowstride;
+        }
+      }
+    }
+    if (!VEC4) {  // scalar gather (Cin not a multiple of 4: the first leg layer at C = 1, 5, ...)
 #pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const int k = kc * KC + 8 * (slot & 3) + 4 * hh;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (VEC4) {
-          if (k < a.K) {
-            const int kh = k / a.KWC;
-            const int x = k - kh * a.KWC;
-            v = *reinterpret_cast<const f32x4*>(a.in + abase[r] + (long long)kh * a.rowstride + x);
-          }
-        } else {
+      for (int r = 0; r < A_SLOTS; ++r) {
+        const int slot = tid + r * NTHREADS;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int k = kc * KC + 8 * (slot & 3) + 4 * hh;
+          f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int kk = k + e;
@@ -127,8 +155,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kerne
               v[e] = a.in[abase[r] + (long long)kh * a.rowstride + x];
             }
           }
+          areg[r][hh] = v;
         }
-        areg[r][hh] = v;
       }
     }
     const unsigned char* wsrc = reinterpret_cast<const unsigned char*>(a.wp) + ((long long)kc * NT + nt0) * 2048;
