@@ -61,19 +61,21 @@ __global__ void conv_prep_bf16_kernel(const float* __restrict__ w, __bf16* __res
   }
 }
 
+// The tiles are passed as __restrict__ pointers so that the compiler keeps treating the three LDS regions as
+// disjoint when they are carved out of one dynamic allocation (without it the ds_write/ds_read streams serialise).
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kernel(ConvArgsB a) {
+__device__ __forceinline__ void conv_mfma_bf16x3_body(const ConvArgsB& a, __bf16* __restrict__ Ah, __bf16* __restrict__ Al,
+                                                      unsigned char* __restrict__ Bs) {
   constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
   constexpr int BM = 16 * WM * WAVES_M;
   constexpr int BN = 16 * WN * WAVES_N;
+  constexpr int ATILE = BM * A_STRIDE;   // bf16 elements per A buffer
+  constexpr int BTILE = BN * 128;        // bytes per B buffer
   constexpr int A_SLOTS = (BM * 4) / NTHREADS;                 // 8-float slots of A per thread per chunk
   constexpr int B_VEC = BN * 8;                                // 16-byte slots of B per chunk (hi + lo)
   constexpr int B_PER_THREAD = (B_VEC + NTHREADS - 1) / NTHREADS;
   static_assert((BM * 4) % NTHREADS == 0, "A tile must divide evenly");
 
-  __shared__ __attribute__((aligned(16))) __bf16 Ah[2][BM * A_STRIDE];
-  __shared__ __attribute__((aligned(16))) __bf16 Al[2][BM * A_STRIDE];
-  __shared__ __attribute__((aligned(16))) unsigned char Bs[2][BN * 128];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -176,13 +178,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kerne
       split_pair_rne(areg[r][1][0], areg[r][1][1], h2, l2);
       split_pair_rne(areg[r][1][2], areg[r][1][3], h3, l3);
       const int off = (slot >> 2) * A_STRIDE + 8 * (slot & 3);
-      *reinterpret_cast<u32x4*>(&Ah[buf][off]) = (u32x4){h0, h1, h2, h3};
-      *reinterpret_cast<u32x4*>(&Al[buf][off]) = (u32x4){l0, l1, l2, l3};
+      *reinterpret_cast<u32x4*>(&Ah[buf * ATILE + off]) = (u32x4){h0, h1, h2, h3};
+      *reinterpret_cast<u32x4*>(&Al[buf * ATILE + off]) = (u32x4){l0, l1, l2, l3};
     }
 #pragma unroll
     for (int r = 0; r < B_PER_THREAD; ++r) {
       const int slot = tid + r * NTHREADS;
-      if (slot < B_VEC) *reinterpret_cast<f32x4*>(&Bs[buf][16 * slot]) = breg[r];
+      if (slot < B_VEC) *reinterpret_cast<f32x4*>(&Bs[buf * BTILE + 16 * slot]) = breg[r];
     }
   };
 
@@ -205,14 +207,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kerne
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int off = ((wave_m * WM + i) * 16 + lrow) * A_STRIDE + 8 * g;
-      ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[cur][off]);
-      al[i] = *reinterpret_cast<const bf16x8*>(&Al[cur][off]);
+      ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[cur * ATILE + off]);
+      al[i] = *reinterpret_cast<const bf16x8*>(&Al[cur * ATILE + off]);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int off = (((wave_n * WN + j) * 2) * 64 + lane) * 16;
-      bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][off]);
-      bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur][off + 1024]);
+      bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BTILE + off]);
+      bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BTILE + off + 1024]);
     }
     // term-major so that consecutive MFMAs never chain on the same accumulator
 #pragma unroll
@@ -250,6 +252,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kerne
       }
     }
   }
+}
+
+// static LDS (<= 64 KB): the common tiles
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kernel(ConvArgsB a) {
+  constexpr int BM = 16 * WM * WAVES_M;
+  constexpr int BN = 16 * WN * WAVES_N;
+  __shared__ __attribute__((aligned(16))) __bf16 Ah[2 * BM * A_STRIDE];
+  __shared__ __attribute__((aligned(16))) __bf16 Al[2 * BM * A_STRIDE];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BN * 128];
+  conv_mfma_bf16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, Ah, Al, Bs);
+}
+
+// dynamic LDS: [Ah 2 x BM x A_STRIDE][Al same][Bs 2 x BN x 128 B] (the 128 x 128 tile needs 72 KB > the 64 KB static limit)
+template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_dyn_kernel(ConvArgsB a) {
+  constexpr int BM = 16 * WM * WAVES_M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
+  conv_mfma_bf16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, reinterpret_cast<__bf16*>(conv_smem),
+                                                        reinterpret_cast<__bf16*>(conv_smem) + 2 * BM * A_STRIDE,
+                                                        conv_smem + 4 * BM * A_STRIDE * sizeof(__bf16));
 }
 
 // Split-K variant for launches with few output rows (a single scan's leg: M = 360..2490 rows against K up to 2304).
@@ -361,10 +384,26 @@ int launch_conv_b(const ConvArgsB& a, bool vec4, hipStream_t stream) {
   constexpr int BN = 16 * WN * WAVES_N;
   dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
   dim3 block(64 * WAVES_M * WAVES_N);
-  if (vec4)
-    hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, 0, stream, a);
-  else
-    hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, 0, stream, a);
+  constexpr size_t lds = 4 * (size_t)BM * A_STRIDE * sizeof(__bf16) + 2 * (size_t)BN * 128;
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    if (vec4)
+      hipLaunchKernelGGL((conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, lds, stream, a);
+    else
+      hipLaunchKernelGGL((conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, lds, stream, a);
+  } else {
+    if (vec4)
+      hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, 0, stream, a);
+    else
+      hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, 0, stream, a);
+  }
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -426,6 +465,10 @@ int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int 
     case 32: return launch_conv_b<2, 2, 4, 1>(a, vec4, stream);
     case 64: return launch_conv_b<2, 4, 4, 1>(a, vec4, stream);
     default:
+      // many output rows (c_conv3 of a sweep: 495 k rows): 128 x 128 tile, 8 waves of 32 x 64 -- each staged weight tile
+      // (16 KB through the ~79 B/clk LDS store path) is shared by twice as many rows and a barrier covers twice the
+      // MFMAs; 0.90 vs 1.08 ms for 1024 pairs.  72 KB of LDS, hence the dynamic-LDS kernel.
+      if (L.cout % 128 == 0 && a.M >= 128ll * 1024) return launch_conv_b<2, 4, 4, 2>(a, vec4, stream);
       if (L.cout % 128 == 0) return launch_conv_b<2, 4, 2, 2>(a, vec4, stream);
       return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);
   }
