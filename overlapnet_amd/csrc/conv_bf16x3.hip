@@ -468,7 +468,8 @@ int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int 
       // many output rows (c_conv3 of a sweep: 495 k rows): 128 x 128 tile, 8 waves of 32 x 64 -- each staged weight tile
       // (16 KB through the ~79 B/clk LDS store path) is shared by twice as many rows and a barrier covers twice the
       // MFMAs; 0.90 vs 1.08 ms for 1024 pairs.  72 KB of LDS, hence the dynamic-LDS kernel.
-      if (L.cout % 128 == 0 && a.M >= 128ll * 1024) return launch_conv_b<2, 4, 4, 2>(a, vec4, stream);
+      static const long long big_m = getenv("OVN_CONV_BIG_M") ? atoll(getenv("OVN_CONV_BIG_M")) : 32ll * 1024;
+      if (L.cout % 128 == 0 && a.M >= big_m) return launch_conv_b<2, 4, 4, 2>(a, vec4, stream);
       if (L.cout % 128 == 0) return launch_conv_b<2, 4, 2, 2>(a, vec4, stream);
       return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);
   }
