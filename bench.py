@@ -269,12 +269,26 @@ def main():
             ov = res[0][:k].float().cpu().numpy()
             yw = res[1][:k].cpu().numpy()
             # end to end: fp64 oracle leg on the same images, then fp64 heads (l = candidate, r = query)
-            all_imgs = np.concatenate([acc_imgs[:k], query_img.cpu().numpy()], axis=0)
+            if raw is not None:
+                # fullstack: the step started from raw clouds -> the oracle starts from the same clouds (its own
+                # projection + normals + channel stacking; fp64 trig rounded to fp32 like the HIP kernel)
+                offs = raw[1].cpu().numpy()
+                sel = list(range(k)) + [P]
+                rows = []
+                for i in sel:
+                    pts_i = raw[0][int(offs[i]):int(offs[i + 1])].cpu().numpy()
+                    rng_i, vtx_i, itn_i, _ = O.range_projection(pts_i, trig64=True)
+                    nrm_i = O.gen_normal_map(rng_i, vtx_i)
+                    rows.append(S.stack(rng_i, nrm_i, itn_i, flags))
+                all_imgs = np.stack(rows)
+                out["accuracy_scope"] = "raw clouds -> projection -> leg -> heads vs fp64 oracle (own projection)"
+            else:
+                all_imgs = np.concatenate([acc_imgs[:k], query_img.cpu().numpy()], axis=0)
             ofv = O.leg_forward(all_imgs, w, S.REFERENCE_MODEL_CFG, np.float64)
             fl = ofv[:k]
             fr = np.repeat(ofv[k:k + 1], k, axis=0)
             o_ov, o_yaw, _, _ = O.heads_forward(fl, fr, w)
-            out["accuracy_scope"] = "images -> leg -> heads vs fp64 oracle"
+            out.setdefault("accuracy_scope", "images -> leg -> heads vs fp64 oracle")
             out["overlap_mae_vs_oracle"] = float(np.mean(np.abs(ov - o_ov)))
             out["overlap_maxerr_vs_oracle"] = float(np.max(np.abs(ov - o_ov)))
             out["yaw_exact_rate"] = float(np.mean(yw == o_yaw))
