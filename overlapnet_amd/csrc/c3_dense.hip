@@ -1,0 +1,227 @@
+// c_conv3 (3x3, 128 -> 256, ReLU) + Flatten + Dense(1) fused, input patch resident in LDS, for gfx950.
+//
+// Reference: generateNet.py:108-114 (Conv2D(256,(3,3),relu) -> Flatten -> Dense(1, sigmoid)).
+// The generic implicit-GEMM kernel (conv_bf16x3.hip) gathers every o2 element 18 times (9 taps x 2 column blocks), splits it
+// into bf16 hi/lo each time and pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a
+// workgroup owns a band of output rows of ONE pair (22 rows = bands of 8, 7, 7): its input patch ((rows+2) x 24 pixels x 128
+// channels) is loaded and split ONCE into an LDS-resident hi/lo image (pixel stride 272 B = 17 16-byte slots: conflict-free
+// ds_read_b128 for 16 consecutive pixels), and the 3x3 taps are just address offsets into it -- no re-staging and no barrier
+// in the 36-step K loop (9 taps x 4 channel chunks of 32).  The 8 waves split the 256 output channels (2 n-tiles each), every
+// wave walks all m-tiles (8 x 22 = 176 pixels = 11 exact tiles), 66 MFMAs per K step against 4 weight-fragment loads straight
+// from L2 (prefetched one step ahead).  The Dense dot product is taken in the epilogue on the accumulators (o3 never goes to
+// HBM unless asked for): per-band partial sums, combined in a fixed order by dense_finish_kernel (deterministic).
+#include "ovn_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int G = OVN_G;                 // 24 input rows / cols
+constexpr int OW = OVN_O3_HW;            // 22 output rows / cols
+constexpr int CI = OVN_C2_OUT;           // 128 input channels
+constexpr int CO = OVN_C3_OUT;           // 256 output channels
+constexpr int PSTRIDE = CI + 8;          // bf16 elements per pixel in LDS (272 B)
+constexpr int NBAND = 3;                 // output-row bands per pair: [0,8) [8,15) [15,22)
+constexpr int MAX_ROWS = 8;
+constexpr int MAX_MT = (MAX_ROWS * OW + 15) / 16;          // 11 m-tiles
+constexpr int IN_PIX_MAX = (MAX_ROWS + 2) * G;             // 240 input pixels
+constexpr size_t LDS_BYTES = 2 * (size_t)IN_PIX_MAX * PSTRIDE * sizeof(__bf16) + 64;   // hi + lo images + reduction scratch
+constexpr int NW = 8;
+
+__device__ __forceinline__ int band_start(int b) { return b == 0 ? 0 : (b == 1 ? 8 : 15); }
+__device__ __forceinline__ int band_rows(int b) { return b == 0 ? 8 : 7; }
+
+__global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restrict__ o2, const __bf16* __restrict__ wp,
+                                                           const float* __restrict__ b3, const float* __restrict__ wd,
+                                                           float* __restrict__ partial, float* __restrict__ o3) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __bf16* ih = reinterpret_cast<__bf16*>(smem);
+  __bf16* il = ih + IN_PIX_MAX * PSTRIDE;
+  float* red = reinterpret_cast<float*>(il + IN_PIX_MAX * PSTRIDE);
+
+  const int pair = blockIdx.x / NBAND;
+  const int band = blockIdx.x - pair * NBAND;
+  const int r0 = band_start(band);
+  const int nrows = band_rows(band);
+  const int npix = nrows * OW;                 // output pixels of this band
+  const int nmt = (npix + 15) >> 4;            // 11 or 10
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  // ---- input patch -> LDS, split once (x = hi + lo, both bf16, round to nearest) ----
+  {
+    const float* src = o2 + ((long long)pair * G + r0) * G * CI;     // rows r0 .. r0 + nrows + 1, contiguous in NHWC
+    const int n4 = (nrows + 2) * G * CI / 4;
+    for (int i = tid; i < n4; i += 64 * NW) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
+      const int pix = i / (CI / 4);
+      const int c = 4 * (i - pix * (CI / 4));
+      bf16x4 h, l;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        h[e] = (__bf16)v[e];
+        l[e] = (__bf16)(v[e] - (float)h[e]);
+      }
+      *reinterpret_cast<bf16x4*>(ih + pix * PSTRIDE + c) = h;
+      *reinterpret_cast<bf16x4*>(il + pix * PSTRIDE + c) = l;
+    }
+  }
+
+  // per m-tile: LDS offset of this lane's output pixel at tap (0,0), channel group 8g
+  int abase[MAX_MT];
+#pragma unroll
+  for (int mt = 0; mt < MAX_MT; ++mt) {
+    int p = 16 * mt + lrow;
+    if (p >= npix) p = npix - 1;               // padded rows of the last tile recompute the last pixel (never stored)
+    const int oy = p / OW;
+    const int ox = p - oy * OW;
+    abase[mt] = (oy * G + ox) * PSTRIDE + 8 * g;
+  }
+
+  f32x4 acc[MAX_MT][2];
+#pragma unroll
+  for (int mt = 0; mt < MAX_MT; ++mt) {
+    acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  // weight fragments: wp[kc][nt(16)][hi,lo][lane][8], kc = tap * 4 + channel chunk; this wave's n-tiles 2w, 2w+1
+  const __bf16* wsrc = wp + ((size_t)(2 * wave) * 2) * 512 + lane * 8;
+  bf16x8 bq[3][4];   // weight fragments of three K steps in flight (an L2 round trip is longer than one step)
+#define C3_LOAD_B(DST, KC)                                                                  \
+  {                                                                                         \
+    const __bf16* q = wsrc + (size_t)(KC) * (16 * 2 * 512);                                 \
+    DST[0] = *reinterpret_cast<const bf16x8*>(q);                                           \
+    DST[1] = *reinterpret_cast<const bf16x8*>(q + 512);                                     \
+    DST[2] = *reinterpret_cast<const bf16x8*>(q + 1024);                                    \
+    DST[3] = *reinterpret_cast<const bf16x8*>(q + 1536);                                    \
+  }
+// m-tiles go two at a time and term-major, so that consecutive MFMAs never chain on one accumulator (4 apart)
+#define C3_MFMA2(M0, M1, A0H, A0L, A1H, A1L, SRC)                                                  \
+  acc[M0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[0], acc[M0][0], 0, 0, 0);          \
+  acc[M0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[2], acc[M0][1], 0, 0, 0);          \
+  acc[M1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[0], acc[M1][0], 0, 0, 0);          \
+  acc[M1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[2], acc[M1][1], 0, 0, 0);          \
+  acc[M0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0L, SRC[0], acc[M0][0], 0, 0, 0);          \
+  acc[M0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0L, SRC[2], acc[M0][1], 0, 0, 0);          \
+  acc[M1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1L, SRC[0], acc[M1][0], 0, 0, 0);          \
+  acc[M1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1L, SRC[2], acc[M1][1], 0, 0, 0);          \
+  acc[M0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[1], acc[M0][0], 0, 0, 0);          \
+  acc[M0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[3], acc[M0][1], 0, 0, 0);          \
+  acc[M1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[1], acc[M1][0], 0, 0, 0);          \
+  acc[M1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[3], acc[M1][1], 0, 0, 0);
+// A fragments are read one tile pair ahead of the MFMAs that consume them (the LDS round trip hides behind 12 MFMAs)
+#define C3_READ_A(BUF, SLOT, MT)                                                            \
+  fh[BUF][SLOT] = *reinterpret_cast<const bf16x8*>(ih + abase[MT] + toff);                  \
+  fl[BUF][SLOT] = *reinterpret_cast<const bf16x8*>(il + abase[MT] + toff);
+#define C3_STEP(SRC, KC)                                                                    \
+  {                                                                                         \
+    const int tap = (KC) >> 2;                                                              \
+    const int ky = tap / 3;                                                                 \
+    const int toff = (ky * G + (tap - 3 * ky)) * PSTRIDE + 32 * ((KC) & 3);                 \
+    bf16x8 fh[2][2], fl[2][2];                                                              \
+    C3_READ_A(0, 0, 0)                                                                      \
+    C3_READ_A(0, 1, 1)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < MAX_MT / 2; ++q) {                                \
+      const int cb = q & 1, nb = cb ^ 1;                                                    \
+      if (q + 1 < MAX_MT / 2) {                                                             \
+        C3_READ_A(nb, 0, 2 * q + 2)                                                         \
+        C3_READ_A(nb, 1, 2 * q + 3)                                                         \
+      } else if (nmt == MAX_MT) {                                                           \
+        C3_READ_A(nb, 0, MAX_MT - 1)                                                        \
+      }                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);  /* keep the reads ahead of the MFMAs they do not feed */ \
+      C3_MFMA2(2 * q, 2 * q + 1, fh[cb][0], fl[cb][0], fh[cb][1], fl[cb][1], SRC)           \
+      __builtin_amdgcn_sched_barrier(0);                                                    \
+    }                                                                                       \
+    if (nmt == MAX_MT) {  /* the 8-row band has an 11th tile */                             \
+      const bf16x8 ah = fh[(MAX_MT / 2) & 1][0], al = fl[(MAX_MT / 2) & 1][0];              \
+      acc[MAX_MT - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[0], acc[MAX_MT - 1][0], 0, 0, 0); \
+      acc[MAX_MT - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[2], acc[MAX_MT - 1][1], 0, 0, 0); \
+      acc[MAX_MT - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, SRC[0], acc[MAX_MT - 1][0], 0, 0, 0); \
+      acc[MAX_MT - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, SRC[2], acc[MAX_MT - 1][1], 0, 0, 0); \
+      acc[MAX_MT - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[1], acc[MAX_MT - 1][0], 0, 0, 0); \
+      acc[MAX_MT - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[3], acc[MAX_MT - 1][1], 0, 0, 0); \
+    }                                                                                       \
+  }
+  C3_LOAD_B(bq[0], 0)
+  C3_LOAD_B(bq[1], 1)
+  __syncthreads();  // patch complete
+#pragma unroll 1
+  for (int kc = 0; kc < 36; kc += 3) {
+    C3_LOAD_B(bq[2], kc + 2)
+    C3_STEP(bq[0], kc)
+    if (kc + 3 < 36) C3_LOAD_B(bq[0], kc + 3)
+    C3_STEP(bq[1], kc + 1)
+    if (kc + 4 < 36) C3_LOAD_B(bq[1], kc + 4)
+    C3_STEP(bq[2], kc + 2)
+  }
+#undef C3_LOAD_B
+#undef C3_STEP
+#undef C3_MFMA2
+#undef C3_READ_A
+
+  // ---- epilogue: bias + ReLU, optional o3 store, Dense partial.  C/D: lane holds channel lrow of each n-tile, rows 4g..4g+3
+  float s = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int n = 32 * wave + 16 * nt + lrow;
+    const float bv = b3[n];
+#pragma unroll
+    for (int mt = 0; mt < MAX_MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int p = 16 * mt + 4 * g + r;
+        if (p < npix) {
+          const float v = fmaxf(acc[mt][nt][r] + bv, 0.0f);
+          const long long fi = (long long)(r0 * OW + p) * CO + n;     // Flatten index (H, W, C) of this value
+          s += v * wd[fi];
+          if (o3) o3[(long long)pair * OVN_DENSE_IN + fi] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) {
+    partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  }
+}
+
+__global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bd, int n,
+                                                           float* __restrict__ overlap, float* __restrict__ logit) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float z = ((partial[NBAND * p] + partial[NBAND * p + 1]) + partial[NBAND * p + 2]) + bd[0];
+  if (logit) logit[p] = z;
+  overlap[p] = 1.0f / (1.0f + expf(-z));
+}
+
+}  // namespace
+
+// o2 (n,24,24,128) fp32 -> partial (3 n) Dense partial sums per output-row band [+ o3 (n,22,22,256) when not NULL];
+// ovn_dense_finish_forward turns the partials into logit / overlap.
+int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, int n, float* partial, float* o3, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c3_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)LDS_BYTES));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(c3_dense_kernel, dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
+                     reinterpret_cast<const __bf16*>(ctx->c3.wp_bf), ctx->c3.bias, ctx->wd, partial, o3);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+int ovn_dense_finish_forward(const ovn_ctx* ctx, const float* partial, int n, float* overlap, float* logit, hipStream_t stream) {
+  hipLaunchKernelGGL(dense_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partial, ctx->bd, n, overlap, logit);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}

@@ -275,13 +275,18 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   const int64_t chunk = 2048;                                   // pairs per pass: 1.6 GB of scratch
   const int64_t cmax = n < chunk ? n : chunk;
   const size_t o2_bytes = ((size_t)cmax * o2_elems * sizeof(float) + 255) & ~(size_t)255;
-  const size_t o3_bytes = ((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255;
+  // second scratch region: o3 (n,22,22,256) in fp32 mode; in bf16x3 mode c_conv3 and the Dense layer are one kernel and only
+  // 3 partial sums per pair leave it
+  const bool fused = (ctx->head_mode != 0);
+  const size_t o3_bytes = fused ? (((size_t)cmax * 3 * sizeof(float) + 255) & ~(size_t)255)
+                                : (((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255);
   int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes, stream);
   if (rc) return rc;
   float* o2 = reinterpret_cast<float*>(ctx->ws);
   float* o3 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + o2_bytes);
   ctx->dbg_o2 = o2;
-  ctx->dbg_o3 = o3;
+  ctx->dbg_o3 = fused ? nullptr : o3;
+  ctx->dbg_partial = fused ? o3 : nullptr;
   ctx->dbg_n = cmax;
   for (int64_t p0 = 0; p0 < n; p0 += chunk) {
     const int np = (int)((n - p0 < chunk) ? (n - p0) : chunk);
@@ -299,14 +304,21 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
                                  : ovn_delta_c12_bf16x3_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
     }
     if (rc) return rc;
-    int oh = 0, ow = 0;
-    {
-      OvnProfScope ps(ctx, OVN_K_C3, stream);
-      rc = (ctx->head_mode == 0) ? ovn_conv_forward(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream)
-                                 : ovn_conv_forward_bf16x3(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream);
-    }
-    if (rc) return rc;
-    {
+    if (fused) {
+      {
+        OvnProfScope ps(ctx, OVN_K_C3, stream);
+        rc = ovn_c3_dense_forward(ctx, o2, np, o3, nullptr, stream);
+      }
+      if (rc) return rc;
+      OvnProfScope ps(ctx, OVN_K_DENSE, stream);
+      rc = ovn_dense_finish_forward(ctx, o3, np, overlap + p0, logit ? logit + p0 : nullptr, stream);
+    } else {
+      int oh = 0, ow = 0;
+      {
+        OvnProfScope ps(ctx, OVN_K_C3, stream);
+        rc = ovn_conv_forward(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream);
+      }
+      if (rc) return rc;
       OvnProfScope ps(ctx, OVN_K_DENSE, stream);
       rc = ovn_dense_sigmoid_forward(ctx, o3, np, overlap + p0, logit ? logit + p0 : nullptr, stream);
     }
@@ -460,9 +472,11 @@ int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3
   if (o2_dev)
     OVN_HIP_CHECK(hipMemcpyAsync(o2_dev, ctx->dbg_o2, (size_t)n * OVN_G * OVN_G * OVN_C2_OUT * sizeof(float),
                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
-  if (o3_dev)
+  if (o3_dev && ctx->dbg_o3)
     OVN_HIP_CHECK(hipMemcpyAsync(o3_dev, ctx->dbg_o3, (size_t)n * OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));
+  else if (o3_dev)  // bf16x3 mode: o3 never left the fused kernel -- run it again on the o2 still in scratch, with o3 output
+    return ovn_c3_dense_forward(ctx, ctx->dbg_o2, (int)n, ctx->dbg_partial, o3_dev, (hipStream_t)stream);
   return OVN_OK;
 }
 

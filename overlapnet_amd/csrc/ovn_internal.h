@@ -90,7 +90,8 @@ struct ovn_ctx {
   };
   std::vector<ProfRec> prof_recs;
   const float* dbg_o2 = nullptr;
-  const float* dbg_o3 = nullptr;
+  const float* dbg_o3 = nullptr;   // fp32 head mode only; in bf16x3 mode o3 is recomputed on request (dbg_partial = scratch)
+  float* dbg_partial = nullptr;
   int64_t dbg_n = 0;
 };
 
@@ -150,6 +151,10 @@ int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* fea
 // corr_spectral.hip
 int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
+// c3_dense.hip: c_conv3 + Flatten + Dense fused (bf16x3 mode), input patch resident in LDS
+int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, int n, float* partial, float* o3, hipStream_t stream);
+int ovn_dense_finish_forward(const ovn_ctx* ctx, const float* partial, int n, float* overlap, float* logit, hipStream_t stream);
+
 // overlap_gt.hip
 int ovn_gt_range_forward(const float* points, const int64_t* offsets, int n_scans, long long max_points, const double* ref_poses,
                          const double* inv_cur_pose, int H, int W, double fov_up_deg, double fov_down_deg, double max_range,
