@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
       // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
       // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
-      constexpr int GB = 5, NB = K2 / 32 / GB;
+      constexpr int GB = 3, NB = K2 / 32 / GB;
       static_assert(NB % 2 == 0, "the batch loop is unrolled by two");
       bf16x8 wq0[GB][2], wq1[GB][2];
       auto ksof = [&](int kk) { const int ks = kk + ks0; return ks >= K2 / 32 ? ks - K2 / 32 : ks; };
@@ -324,19 +324,30 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     DST[u][0] = *reinterpret_cast<const bf16x8*>(wk);                              \
     DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512);                        \
   }
+// o1 fragments are read from LDS one k-step ahead of the MFMAs that consume them
+#define OVN_W2_READ_A(SLOT, B, U)                                                  \
+  {                                                                                \
+    const int ks_ = ksof((B) * GB + (U));                                          \
+    af[SLOT][0] = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks_);                \
+    af[SLOT][1] = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks_);                \
+    af[SLOT][2] = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks_);                \
+    af[SLOT][3] = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks_);                \
+  }
 #define OVN_W2_COMPUTE(SRC, B)                                                     \
-  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
-    const int ks = ksof((B) * GB + u);                                             \
-    const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);            \
-    const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);            \
-    const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);            \
-    const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);            \
-    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][0], acc2[0], 0, 0, 0); \
-    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][0], acc2[1], 0, 0, 0); \
-    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, SRC[u][0], acc2[0], 0, 0, 0); \
-    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, SRC[u][0], acc2[1], 0, 0, 0); \
-    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][1], acc2[0], 0, 0, 0); \
-    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][1], acc2[1], 0, 0, 0); \
+  {                                                                                \
+    bf16x8 af[2][4];                                                               \
+    OVN_W2_READ_A(0, B, 0)                                                         \
+    _Pragma("unroll") for (int u = 0; u < GB; ++u) {                               \
+      if (u + 1 < GB) OVN_W2_READ_A((u + 1) & 1, B, u + 1)                         \
+      __builtin_amdgcn_sched_barrier(0);                                           \
+      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][0], acc2[0], 0, 0, 0); \
+      acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][0], acc2[1], 0, 0, 0); \
+      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], SRC[u][0], acc2[0], 0, 0, 0); \
+      acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][3], SRC[u][0], acc2[1], 0, 0, 0); \
+      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][1], acc2[0], 0, 0, 0); \
+      acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][1], acc2[1], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                           \
+    }                                                                              \
   }
       OVN_W2_LOAD(wq0, 0)
 #pragma unroll 1
@@ -350,6 +361,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       }
 #undef OVN_W2_LOAD
 #undef OVN_W2_COMPUTE
+#undef OVN_W2_READ_A
       const int p = 16 * wave + lrow;
       const float bv = b2[p];
 #pragma unroll
