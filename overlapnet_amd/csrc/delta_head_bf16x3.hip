@@ -308,9 +308,13 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       const __bf16* a1h = o1h + ib1 * O1_STRIDE + 8 * g;
       const __bf16* a1l = o1l + ib1 * O1_STRIDE + 8 * g;
       const __bf16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;
-      f32x4 acc2[2];
-      acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // one accumulator per (m-tile, split term): six independent MFMA chains per k-step instead of two -- with only two
+      // accumulators every MFMA waited on the one issued two before it (this wave's whole GEMM2 is 2 x 1 tiles)
+      f32x4 acc2t[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc2t[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
       // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
       // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
@@ -340,12 +344,12 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     _Pragma("unroll") for (int u = 0; u < GB; ++u) {                               \
       if (u + 1 < GB) OVN_W2_READ_A((u + 1) & 1, B, u + 1)                         \
       __builtin_amdgcn_sched_barrier(0);                                           \
-      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][0], acc2[0], 0, 0, 0); \
-      acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][0], acc2[1], 0, 0, 0); \
-      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], SRC[u][0], acc2[0], 0, 0, 0); \
-      acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][3], SRC[u][0], acc2[1], 0, 0, 0); \
-      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][1], acc2[0], 0, 0, 0); \
-      acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][1], acc2[1], 0, 0, 0); \
+      acc2t[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][0], acc2t[0][0], 0, 0, 0); \
+      acc2t[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][0], acc2t[1][0], 0, 0, 0); \
+      acc2t[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], SRC[u][0], acc2t[0][1], 0, 0, 0); \
+      acc2t[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][3], SRC[u][0], acc2t[1][1], 0, 0, 0); \
+      acc2t[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][1], acc2t[0][2], 0, 0, 0); \
+      acc2t[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][1], acc2t[1][2], 0, 0, 0); \
       __builtin_amdgcn_sched_barrier(0);                                           \
     }                                                                              \
   }
@@ -362,6 +366,9 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
 #undef OVN_W2_LOAD
 #undef OVN_W2_COMPUTE
 #undef OVN_W2_READ_A
+      f32x4 acc2[2];
+      acc2[0] = (acc2t[0][0] + acc2t[0][1]) + acc2t[0][2];
+      acc2[1] = (acc2t[1][0] + acc2t[1][1]) + acc2t[1][2];
       const int p = 16 * wave + lrow;
       const float bv = b2[p];
 #pragma unroll

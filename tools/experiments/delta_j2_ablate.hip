@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     if (j == 1) __syncthreads();  // GEMM2 of the first group is done with the o1 image
     // o1 (+ bias) -> LDS as hi/lo bf16 in GEMM2's A layout (K order k' = di*64 + 4*lrow + nt, see the W2 prep kernel).
     // C/D: lane holds column lrow of every n-tile, rows 4g..4g+3: one 8-byte store for the 4 hi parts, one for the lo parts.
-    {
+    if (!(ABL & 512)) {
       float bv[4];
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bv[nt] = b1[16 * nt + lrow];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
 
     // GEMM2 (24 x 960) x (960 x 128): wave w owns output columns 16w..16w+15 for BOTH 16-row m-tiles, so every
     // W2 fragment is fetched from L2 by exactly one wave of the workgroup (491 KB per column group, not 2x that).
-    if (wave < 8) {
+    if (wave < 8 && !(ABL & 256)) {
       const int ib0 = lrow;                                   // m-tile 0: rows 0..15
       const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;  // m-tile 1: rows 16..23 (+ 8 padding rows)
       const __bf16* a0h = o1h + ib0 * O1_STRIDE + 8 * g;
@@ -323,35 +323,52 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       const __bf16* a1h = o1h + ib1 * O1_STRIDE + 8 * g;
       const __bf16* a1l = o1l + ib1 * O1_STRIDE + 8 * g;
       const __bf16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;
-      f32x4 acc2[2];
-      acc2[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      // one accumulator per (m-tile, split term): six independent MFMA chains per k-step instead of two -- with only two
+      // accumulators every MFMA waited on the one issued two before it (this wave's whole GEMM2 is 2 x 1 tiles)
+      f32x4 acc2t[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc2t[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
       // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
       // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
-      constexpr int GB = 5, NB = K2 / 32 / GB;
+      constexpr int GB = 3, NB = K2 / 32 / GB;
       static_assert(NB % 2 == 0, "the batch loop is unrolled by two");
       bf16x8 wq0[GB][2], wq1[GB][2];
       auto ksof = [&](int kk) { const int ks = kk + ks0; return ks >= K2 / 32 ? ks - K2 / 32 : ks; };
 #define OVN_W2_LOAD(DST, B)                                                        \
   _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
     const __bf16* wk = wcol + (size_t)ksof((B) * GB + u) * (8 * 2 * 512);          \
+    if (ABL & 1024) { DST[u][0] = fakeb; DST[u][1] = fakeb; } else {               \
     DST[u][0] = *reinterpret_cast<const bf16x8*>(wk);                              \
-    DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512);                        \
+    DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512); }                      \
+  }
+// o1 fragments are read from LDS one k-step ahead of the MFMAs that consume them
+#define OVN_W2_READ_A(SLOT, B, U)                                                  \
+  {                                                                                \
+    const int ks_ = ksof((B) * GB + (U));                                          \
+    if (ABL & 2048) { af[SLOT][0] = fakeb; af[SLOT][1] = fakeb; af[SLOT][2] = fakeb; af[SLOT][3] = fakeb; } else \
+    af[SLOT][0] = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks_);                \
+    af[SLOT][1] = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks_);                \
+    af[SLOT][2] = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks_);                \
+    af[SLOT][3] = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks_);                \
   }
 #define OVN_W2_COMPUTE(SRC, B)                                                     \
-  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
-    const int ks = ksof((B) * GB + u);                                             \
-    const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks);            \
-    const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(a0l + 32 * ks);            \
-    const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(a1h + 32 * ks);            \
-    const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(a1l + 32 * ks);            \
-    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][0], acc2[0], 0, 0, 0); \
-    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][0], acc2[1], 0, 0, 0); \
-    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, SRC[u][0], acc2[0], 0, 0, 0); \
-    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, SRC[u][0], acc2[1], 0, 0, 0); \
-    acc2[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, SRC[u][1], acc2[0], 0, 0, 0); \
-    acc2[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, SRC[u][1], acc2[1], 0, 0, 0); \
+  {                                                                                \
+    bf16x8 af[2][4];                                                               \
+    OVN_W2_READ_A(0, B, 0)                                                         \
+    _Pragma("unroll") for (int u = 0; u < GB; ++u) {                               \
+      if (u + 1 < GB) OVN_W2_READ_A((u + 1) & 1, B, u + 1)                         \
+      __builtin_amdgcn_sched_barrier(0);                                           \
+      acc2t[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][0], acc2t[0][0], 0, 0, 0); \
+      acc2t[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][0], acc2t[1][0], 0, 0, 0); \
+      acc2t[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][1], SRC[u][0], acc2t[0][1], 0, 0, 0); \
+      acc2t[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][3], SRC[u][0], acc2t[1][1], 0, 0, 0); \
+      acc2t[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][0], SRC[u][1], acc2t[0][2], 0, 0, 0); \
+      acc2t[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[u & 1][2], SRC[u][1], acc2t[1][2], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                           \
+    }                                                                              \
   }
       OVN_W2_LOAD(wq0, 0)
 #pragma unroll 1
@@ -365,6 +382,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       }
 #undef OVN_W2_LOAD
 #undef OVN_W2_COMPUTE
+#undef OVN_W2_READ_A
+      f32x4 acc2[2];
+      acc2[0] = (acc2t[0][0] + acc2t[0][1]) + acc2t[0][2];
+      acc2[1] = (acc2t[1][0] + acc2t[1][1]) + acc2t[1][2];
       const int p = 16 * wave + lrow;
       const float bv = b2[p];
 #pragma unroll
@@ -433,5 +454,9 @@ int main() {
   RUN(64 + 8, "no epilogue, no B LDS reads")
   RUN(64 + 16, "no epilogue, no split")
   RUN(64 + 32, "no epilogue, no MFMA")
+  RUN(256, "no GEMM2 (o1 split + stores + barriers kept)")
+  RUN(1024, "GEMM2 without W2 loads (constant fragments)")
+  RUN(2048, "GEMM2 without o1 LDS reads (first fragment only)")
+  RUN(1024 + 2048, "GEMM2 MFMAs only")
   return 0;
 }

@@ -2,7 +2,7 @@
 """Generates tools/experiments/delta_j2_ablate.hip from the product kernel (timing-only ablation variants).
    python tools/experiments/make_delta_j2_ablate.py && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize \
        tools/experiments/delta_j2_ablate.hip -o tools/bin/delta_j2_ablate
-ABL bits: 1 no W1 staging, 2 no slice barriers, 8 no B LDS reads (constant fragments), 16 no split (fake A from L + R),
+ABL bits: 256 no GEMM2, 512 no o1 split/store, 1 no W1 staging, 2 no slice barriers, 8 no B LDS reads (constant fragments), 16 no split (fake A from L + R),
 32 no MFMA, 64 no epilogue/GEMM2, 128 no L reloads.  (Making R or L loop-invariant is NOT a valid ablation: the
 compiler hoists the split out of the step loop.)"""
 import os
@@ -74,6 +74,12 @@ kern = rep(kern, '''#pragma unroll
     for (int j = 0; j < 2; ++j) {
     const int jb = 2 * jb2 + j;''')
 kern = rep(kern, "  int cur = 0;\n", "  int cur = 0;\n  bf16x8 fakeb = __builtin_bit_cast(bf16x8, la[1][0]);\n")
+kern = rep(kern, "    if (wave < 8) {\n      const int ib0 = lrow;", "    if (wave < 8 && !(ABL & 256)) {\n      const int ib0 = lrow;")
+kern = rep(kern, "    {\n      float bv[4];", "    if (!(ABL & 512)) {\n      float bv[4];")
+kern = rep(kern, "    DST[u][0] = *reinterpret_cast<const bf16x8*>(wk);                              \\\n    DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512);                        \\",
+           "    if (ABL & 1024) { DST[u][0] = fakeb; DST[u][1] = fakeb; } else {               \\\n    DST[u][0] = *reinterpret_cast<const bf16x8*>(wk);                              \\\n    DST[u][1] = *reinterpret_cast<const bf16x8*>(wk + 512); }                      \\")
+kern = rep(kern, "    af[SLOT][0] = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks_);                \\",
+           "    if (ABL & 2048) { af[SLOT][0] = fakeb; af[SLOT][1] = fakeb; af[SLOT][2] = fakeb; af[SLOT][3] = fakeb; } else \\\n    af[SLOT][0] = *reinterpret_cast<const bf16x8*>(a0h + 32 * ks_);                \\")
 host = r'''
 #undef OVN_LOAD_L
 #undef OVN_SLICE
@@ -127,6 +133,10 @@ int main() {
   RUN(64 + 8, "no epilogue, no B LDS reads")
   RUN(64 + 16, "no epilogue, no split")
   RUN(64 + 32, "no epilogue, no MFMA")
+  RUN(256, "no GEMM2 (o1 split + stores + barriers kept)")
+  RUN(1024, "GEMM2 without W2 loads (constant fragments)")
+  RUN(2048, "GEMM2 without o1 LDS reads (first fragment only)")
+  RUN(1024 + 2048, "GEMM2 MFMAs only")
   return 0;
 }
 '''
