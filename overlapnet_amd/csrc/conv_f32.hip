@@ -31,6 +31,7 @@ struct ConvArgs {
   int K, nkc, KWC, rowstride;
   long long M;
   int relu;
+  int out_cols;  // stored output channels = output row stride (<= Cout)
 };
 
 __global__ void conv_prep_kernel(const float* __restrict__ w, float* __restrict__ wp, int K, int nkc, int Cout) {
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_f32_kernel(C
         if (m < a.M) {
           float v = acc[i][j][r] + bv;
           if (a.relu) v = fmaxf(v, 0.0f);
-          a.out[m * a.Cout + n] = v;
+          if (n < a.out_cols) a.out[m * a.out_cols + n] = v;
         }
       }
     }
@@ -253,6 +254,7 @@ int ovn_conv_forward(const OvnConvLayer& L, const float* in, int nb, int h, int 
   a.rowstride = w * L.cin;
   a.M = (long long)nb * a.OH * a.OW;
   a.relu = L.relu;
+  a.out_cols = L.out_cols > 0 ? L.out_cols : L.cout;
   if (oh_out) *oh_out = a.OH;
   if (ow_out) *ow_out = a.OW;
   if (a.M == 0) return OVN_OK;

@@ -33,6 +33,7 @@ constexpr int SW = OVN_SPEC_W;     // 368 floats per spectrum row
 constexpr int FQ = IM_OFF / 4;     // 46 frequency quads
 constexpr int CG = 4;              // channel groups of 32
 constexpr int PROD_THREADS = 192;  // 184 working threads
+constexpr int SWP = 384;           // SW padded with zero filters to 3 x 128 so the conv kernel can use its 64 x 128 tile
 
 // C^ for one pair: out[pair][f] = Re, out[pair][184 + f] = Im, padding zero.
 __global__ __launch_bounds__(PROD_THREADS) void spectral_product_kernel(const float* __restrict__ spec_l,
@@ -147,16 +148,17 @@ int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream) {
     L.kh = FW;
     L.kw = 1;
     L.cin = 1;
-    L.cout = SW;
+    L.cout = SWP;
+    L.out_cols = SW;
     L.sh = 1;
     L.sw = 1;
     L.relu = 0;
-    std::vector<float> w((size_t)FW * SW, 0.f);
+    std::vector<float> w((size_t)FW * SWP, 0.f);
     for (int i = 0; i < FW; ++i)
       for (int f = 0; f < NF; ++f) {
         const double ang = w0 * (double)((long long)f * i % FW);
-        w[(size_t)i * SW + f] = (float)cos(ang);
-        w[(size_t)i * SW + IM_OFF + f] = (float)(-sin(ang));
+        w[(size_t)i * SWP + f] = (float)cos(ang);
+        w[(size_t)i * SWP + IM_OFF + f] = (float)(-sin(ang));
       }
     int rc = upload_layer(&L, w, stream);
     if (rc) return rc;
@@ -168,17 +170,18 @@ int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream) {
     L.kh = 1;
     L.kw = 1;
     L.cin = SW;
-    L.cout = SW;
+    L.cout = SWP;
+    L.out_cols = SW;
     L.sh = 1;
     L.sw = 1;
     L.relu = 0;
-    std::vector<float> w((size_t)SW * SW, 0.f);
+    std::vector<float> w((size_t)SW * SWP, 0.f);
     for (int f = 0; f < NF; ++f) {
       const double wf = ((f == 0 || f == FW / 2) ? 1.0 : 2.0) / FW;
       for (int k = 0; k < FW; ++k) {
         const double ang = w0 * (double)((long long)f * (k + FW / 2) % FW);
-        w[(size_t)f * SW + k] = (float)(wf * cos(ang));
-        w[(size_t)(IM_OFF + f) * SW + k] = (float)(-wf * sin(ang));
+        w[(size_t)f * SWP + k] = (float)(wf * cos(ang));
+        w[(size_t)(IM_OFF + f) * SWP + k] = (float)(-wf * sin(ang));
       }
     }
     int rc = upload_layer(&L, w, stream);

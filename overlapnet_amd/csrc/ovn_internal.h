@@ -50,6 +50,8 @@ struct OvnConvLayer {
   std::string name;
   int kh = 0, kw = 0, cin = 0, cout = 0, sh = 1, sw = 1;
   int relu = 1;
+  int out_cols = 0;  // 0 = cout; else only the first out_cols output channels are stored, at row stride out_cols
+                     // (a layer padded with zero filters so that a wide tile divides cout: the 368-column DFT layers)
   int K = 0;      // kh*kw*cin
   int nkc = 0;    // ceil(K/16)
   float* wp = nullptr;    // [nkc][cout/16][64][4] fragment-ordered copy (device)
