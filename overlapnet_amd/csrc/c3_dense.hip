@@ -208,12 +208,8 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
 // o2 (n,24,24,128) fp32 -> partial (3 n) Dense partial sums per output-row band [+ o3 (n,22,22,256) when not NULL];
 // ovn_dense_finish_forward turns the partials into logit / overlap.
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, int n, float* partial, float* o3, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(c3_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      (int)LDS_BYTES));
-    attr_set = true;
-  }
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel), LDS_BYTES);
+  if (rc) return rc;
   hipLaunchKernelGGL(c3_dense_kernel, dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
                      reinterpret_cast<const __bf16*>(ctx->c3.wp_bf), ctx->c3.bias, ctx->wd, partial, o3);
   OVN_HIP_CHECK(hipGetLastError());

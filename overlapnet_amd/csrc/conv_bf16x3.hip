@@ -386,14 +386,9 @@ int launch_conv_b(const ConvArgsB& a, bool vec4, hipStream_t stream) {
   dim3 block(64 * WAVES_M * WAVES_N);
   constexpr size_t lds = 4 * (size_t)BM * A_STRIDE * sizeof(__bf16) + 2 * (size_t)BN * 128;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      attr_set = true;
-    }
+    int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), lds);
+    if (!rc) rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>), lds);
+    if (rc) return rc;
     if (vec4)
       hipLaunchKernelGGL((conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, lds, stream, a);
     else

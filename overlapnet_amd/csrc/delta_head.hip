@@ -214,13 +214,9 @@ int ovn_delta_prepare_w1(const float* c1_kernel_dev, float** w1p_out, hipStream_
 
 int ovn_delta_c12_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                           const int32_t* ridx, int n, float* o2, hipStream_t stream) {
-  static bool attr_set = false;
   const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
-  if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_kernel), lds);
+  if (rc) return rc;
   hipLaunchKernelGGL(delta_c12_kernel, dim3(n), dim3(512), lds, stream, feats_l, lidx, feats_r, ridx, ctx->w1p,
                      ctx->b1, ctx->c2.wp, ctx->c2.bias, o2);
   OVN_HIP_CHECK(hipGetLastError());

@@ -391,12 +391,8 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
 
 int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                  const int32_t* ridx, int n, float* o2, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    OVN_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8, false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
-    attr_set = true;
-  }
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8, false>), LDS_BYTES);
+  if (rc) return rc;
   hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8, false>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r,
                      ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
                      ctx->c2.bias, o2, 1);

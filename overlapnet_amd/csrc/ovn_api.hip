@@ -1,10 +1,25 @@
 // extern "C" surface of libovn_hip.so (declared in include/ovn_hip.h) -- argument checking, weight
 // re-tiling, scratch management and the launch sequences.  No torch types anywhere: plain pointers.
 #include <stdarg.h>
+#include <mutex>
+#include <set>
+#include <utility>
 #include <stdio.h>
 #include <string.h>
 
 #include "ovn_internal.h"
+
+int ovn_allow_dynamic_lds(const void* kernel, size_t bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<const void*, int>> done;
+  int dev = 0;
+  OVN_HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lock(mu);
+  if (done.count({kernel, dev})) return OVN_OK;
+  OVN_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  done.insert({kernel, dev});
+  return OVN_OK;
+}
 
 static thread_local char g_err[1024] = "";
 
@@ -116,7 +131,7 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
   OVN_REQUIRE(ctx && c1k && c1b && c2k && c2b && c3k && c3b && dk && db, OVN_ERR_ARG, "ovn_set_head_weights: NULL argument");
   OVN_HIP_CHECK(hipSetDevice(ctx->device));
   hipStream_t stream = (hipStream_t)stream_;
-  if (ctx->head_set) {
+  {  // drop whatever an earlier (possibly half-failed) call left behind
     ovn_conv_release(&ctx->c2);
     ovn_conv_release(&ctx->c3);
     if (ctx->w1p) (void)hipFree(ctx->w1p);

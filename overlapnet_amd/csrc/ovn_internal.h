@@ -46,6 +46,10 @@ constexpr int OVN_SPEC_W = 368;                                 // floats per sp
 constexpr int OVN_SPEC_ELEMS = OVN_FEAT_C * OVN_SPEC_W;        // 47104 floats = 188,416 B per scan
 
 // ---- a convolution layer in MFMA fragment order ----------------------------------------------------
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and one process may hold
+// contexts on several GPUs.  Thread-safe.
+int ovn_allow_dynamic_lds(const void* kernel, size_t bytes);
+
 struct OvnConvLayer {
   std::string name;
   int kh = 0, kw = 0, cin = 0, cout = 0, sh = 1, sw = 1;
