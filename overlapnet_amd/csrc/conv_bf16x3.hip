@@ -444,6 +444,14 @@ int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int 
   if (oh_out) *oh_out = a.OH;
   if (ow_out) *ow_out = a.OW;
   if (a.M == 0) return OVN_OK;
+  {  // many scans of s_conv3 / s_conv3a: input strip resident in LDS (conv_strip.hip)
+    static const int strip = getenv("OVN_CONV_STRIP") ? atoi(getenv("OVN_CONV_STRIP")) : 1;
+    if (strip && !few_rows) {
+      const int took = ovn_conv_strip_try(L, in, nb, h, w, out, stream);
+      if (took < 0) return -took;
+      if (took > 0) return OVN_OK;
+    }
+  }
   const bool vec4 = (L.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   // few output rows (single-scan leg): split K across the waves of 16-row workgroups instead of tiling M
   static const int splitk = getenv("OVN_CONV_SPLITK") ? atoi(getenv("OVN_CONV_SPLITK")) : 1;

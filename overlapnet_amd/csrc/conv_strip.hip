@@ -1,0 +1,253 @@
+// KH x KW / stride (SH,1) convolutions + bias + ReLU with the input strip resident in LDS, for gfx950 (bf16x3 arithmetic).
+//
+// Reference: the leg layers s_conv3 .. s_conv10 (generateNet.py:173-214): 3x15 and 3x12 with stride (2,1) to 64 channels,
+// 2x9 stride (2,1) and the 1xKW layers to 128 channels -- 70 % of the batched leg's time in the generic implicit-GEMM
+// kernel (conv_bf16x3.hip), which gathers and splits every input element once per tap that touches it (up to 22x) and
+// pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a workgroup owns TW output pixels
+// of one output row: the KH input rows it needs ((TW + KW - 1) pixels x CIN channels each) are loaded and split ONCE into
+// an LDS-resident hi/lo strip and every tap is a compile-time address offset into it (the K walk is fully unrolled).
+// Strip layout: one plane per group of 8 channels, [pixel][8 bf16 = 16 B], planes a multiple of 256 B apart: the 16
+// lanes that ds_read_b128 services together (8 lanes of channel group g, 8 of g+1, consecutive pixels) then cover all 64
+// banks exactly once (a pixel-major layout with any padding gives 2-way conflicts).  No barrier in the K loop (KH x KW x
+// CIN/32 steps of 32 channels, exactly the chunk order of the pre-split weights [kc][nt][hi,lo][lane][8]).  8 waves = NT
+// n-tiles x 8/NT groups of m-tiles; weight fragments straight from L2 three steps deep; A fragments for step s+1 are read
+// while step s feeds the matrix pipe.  Same per-accumulator summation order as the generic kernel: bit-identical results.
+#include <stdlib.h>
+
+#include <utility>
+
+#include "ovn_internal.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct StripArgs {
+  const float* in;
+  const __bf16* wp;
+  const float* bias;
+  float* out;
+  int H, W, OH, OW, XT;   // input rows / cols, output rows / cols, x tiles per output row
+};
+
+template <int CIN, int KH, int KW, int TW, int NT>
+struct StripCfg {
+  static constexpr int PIX = TW + KW - 1;              // input pixels per strip row
+  static constexpr int PLANE = (KH * PIX * 8 + 127) / 128 * 128;  // bf16 elements per 8-channel plane (multiple of 256 B)
+  static constexpr int NPL = CIN / 8;                  // planes
+  static constexpr int MT = (TW + 15) / 16;            // m-tiles per workgroup
+  static constexpr int MSPLIT = 8 / NT;                // wave groups along M (8 waves = NT n-tiles x MSPLIT)
+  static constexpr int MTH = (MT + MSPLIT - 1) / MSPLIT;   // m-tiles per wave
+  static constexpr int CC = CIN / 32;                  // 32-channel chunks per tap
+  static constexpr int NK = KH * KW * CC;              // K steps
+  static constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(__bf16) + 1024;   // + slack for padded-row reads
+};
+
+template <int CIN, int KH, int SH, int KW, int TW, int NT>
+__global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
+  typedef StripCfg<CIN, KH, KW, TW, NT> C;
+  constexpr int COUT = 16 * NT;
+  constexpr int PLANE = C::PLANE, PIX = C::PIX, MTH = C::MTH, CC = C::CC, NK = C::NK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
+  __bf16* sh = reinterpret_cast<__bf16*>(strip_smem);
+  __bf16* sl = sh + C::NPL * PLANE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+  const int wn = wave % NT;    // n-tile
+  const int wm = wave / NT;    // group of m-tiles
+
+  int bid = blockIdx.x;
+  const int xt = bid % a.XT;
+  bid /= a.XT;
+  const int oy = bid % a.OH;
+  const int b = bid / a.OH;
+  const int x0 = xt * TW;
+  const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;           // valid output pixels of this tile
+  const int pixv = (a.W - x0 < PIX) ? a.W - x0 : PIX;         // valid input pixels per strip row
+
+  // ---- strip -> LDS, split once ----
+  {
+    constexpr int Q = CIN / 4;                                // float4 groups per pixel
+    constexpr int TOTAL = KH * PIX * Q;
+    constexpr int ITERS = (TOTAL + 511) / 512;
+    // all loads of a batch are issued before the first is consumed (a rolled loop would pay one memory round trip
+    // per iteration: the compiler cannot overlap iterations it does not see)
+    constexpr int BATCH = 6;
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int i = tid + (it0 + u) * 512;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < TOTAL) {
+          const int row = i / (PIX * Q);
+          const int r = i - row * (PIX * Q);
+          const int pix = r / Q;
+          const int c = 4 * (r - pix * Q);
+          if (pix < pixv) v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + x0 + pix) * CIN + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int i = tid + (it0 + u) * 512;
+        if (i < TOTAL) {
+          const int row = i / (PIX * Q);
+          const int r = i - row * (PIX * Q);
+          const int pix = r / Q;
+          const int c = 4 * (r - pix * Q);
+          bf16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            h[e] = (__bf16)v[u][e];
+            l[e] = (__bf16)(v[u][e] - (float)h[e]);
+          }
+          const int o = (c >> 3) * PLANE + (row * PIX + pix) * 8 + (c & 7);
+          *reinterpret_cast<bf16x4*>(sh + o) = h;
+          *reinterpret_cast<bf16x4*>(sl + o) = l;
+        }
+      }
+    }
+  }
+
+  // Fragment addresses: one per-lane base (pixel lrow of the wave's first m-tile, channel group g); m-tile i is 16 pixels
+  // = 256 B further, a tap (ky, kx) and a channel chunk are compile-time offsets because the K loop is fully unrolled
+  // -> no address arithmetic in the loop.  (Rows of the last, partly padded m-tile read a few pixels past the tile; those
+  // accumulators are never stored, and the allocation has slack for the last plane.)
+  const __bf16* ah_base = sh + g * PLANE + (16 * wm * MTH + lrow) * 8;
+  const __bf16* al_base = sl + g * PLANE + (16 * wm * MTH + lrow) * 8;
+  f32x4 acc[MTH];
+#pragma unroll
+  for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // weights [kc][nt(NT)][hi,lo][lane][8]: wave-uniform base (scalar) + one per-lane offset
+  const __bf16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512);
+  const int wlane = lane * 8;
+  bf16x8 bq[3][2];
+  bf16x8 fh[2][MTH], fl[2][MTH];
+#define STRIP_LOAD_B(SLOT, KS)                                                     \
+  {                                                                                \
+    const __bf16* q = wbase + (size_t)(KS) * (NT * 2 * 512);                       \
+    bq[SLOT][0] = *reinterpret_cast<const bf16x8*>(q + wlane);                     \
+    bq[SLOT][1] = *reinterpret_cast<const bf16x8*>(q + 512 + wlane);               \
+  }
+#define STRIP_READ_A(BUF, KS)                                                      \
+  {                                                                                \
+    constexpr int tap_ = (KS) / CC;                                                \
+    constexpr int ky_ = tap_ / KW;                                                 \
+    constexpr int toff_ = (ky_ * PIX + (tap_ - ky_ * KW)) * 8 + 4 * PLANE * ((KS) - tap_ * CC); \
+    _Pragma("unroll") for (int i = 0; i < MTH; ++i) {                              \
+      fh[BUF][i] = *reinterpret_cast<const bf16x8*>(ah_base + toff_ + i * 128);    \
+      fl[BUF][i] = *reinterpret_cast<const bf16x8*>(al_base + toff_ + i * 128);    \
+    }                                                                              \
+  }
+#define STRIP_MFMA(BUF, SLOT)                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
+  _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
+  _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[BUF][i], bq[SLOT][1], acc[i], 0, 0, 0);
+  STRIP_LOAD_B(0, 0)
+  STRIP_LOAD_B(1, 1)
+  __syncthreads();  // strip complete
+  STRIP_READ_A(0, 0)
+  // fully unrolled K walk (compile-time k): 3 weight slots x 2 fragment buffers, everything one step (A) / two steps (B) ahead
+  [&]<int... K>(std::integer_sequence<int, K...>) {
+    (([&] {
+       if constexpr (K + 2 < NK) STRIP_LOAD_B((K + 2) % 3, K + 2)
+       if constexpr (K + 1 < NK) STRIP_READ_A((K + 1) & 1, K + 1)
+       __builtin_amdgcn_sched_barrier(0);
+       STRIP_MFMA(K & 1, K % 3)
+       __builtin_amdgcn_sched_barrier(0);
+     }()),
+     ...);
+  }(std::make_integer_sequence<int, NK>{});
+#undef STRIP_LOAD_B
+#undef STRIP_READ_A
+#undef STRIP_MFMA
+
+  // ---- epilogue: bias + ReLU.  C/D layout: lane holds output channel lrow of its n-tile, rows 4g..4g+3 of each m-tile
+  const int n = 16 * wn + lrow;
+  const float bv = a.bias[n];
+  float* orow = a.out + (((long long)b * a.OH + oy) * a.OW + x0) * COUT;
+#pragma unroll
+  for (int i = 0; i < MTH; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = 16 * (wm * MTH + i) + 4 * g + r;
+      if (p < tw) orow[(long long)p * COUT + n] = fmaxf(acc[i][r] + bv, 0.0f);
+    }
+  }
+}
+
+template <int CIN, int KH, int SH, int KW, int TW, int NT>
+int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, hipStream_t stream, bool* took) {
+  typedef StripCfg<CIN, KH, KW, TW, NT> C;
+  StripArgs a;
+  a.in = in;
+  a.wp = reinterpret_cast<const __bf16*>(L.wp_bf);
+  a.bias = L.bias;
+  a.out = out;
+  a.H = h;
+  a.W = w;
+  a.OH = (h - KH) / SH + 1;
+  a.OW = w - KW + 1;
+  a.XT = (a.OW + TW - 1) / TW;
+  const long long wgs = (long long)nb * a.OH * a.XT;
+  *took = wgs >= 384;                                   // too few workgroups to fill the chip: the generic kernel tiles finer
+  if (!*took) return OVN_OK;
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), C::LDS_BYTES);
+  if (rc) return rc;
+  hipLaunchKernelGGL((conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+}  // namespace
+
+static int pad_rows(int ow, int tw) { return (ow + tw - 1) / tw * tw - ow; }   // padded output pixels per row with tiles of tw
+
+// Returns 1 when the layer / call was taken (result in out), 0 when the caller should use the generic kernel, < 0 on error.
+int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, hipStream_t stream) {
+  if (!(L.sw == 1 && L.relu && L.wp_bf != nullptr) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return 0;
+  if (h < L.kh || w < L.kw) return 0;
+  bool took = false;
+  int rc = OVN_OK;
+  const int key = ((L.kh * 100 + L.kw) * 1000 + L.cin) * 1000 + L.cout;   // kh, kw, cin, cout
+  if (L.kh > 1 && L.sh != 2) return 0;
+  if (L.kh == 1 && L.sh != 1) return 0;
+  switch (key) {
+    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 208, 4>(L, in, nb, h, w, out, stream, &took); break;   // s_conv3
+    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 135, 4>(L, in, nb, h, w, out, stream, &took); break;   // s_conv3a
+    // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
+    case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, h, w, out, stream, &took)
+                                                                 : launch_strip<64, 2, 2, 9, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      break;
+    case ((1 * 100 + 9) * 1000 + 128) * 1000 + 128:   // s_conv5-7
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, h, w, out, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 9, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      break;
+    case ((1 * 100 + 7) * 1000 + 128) * 1000 + 128:   // s_conv8
+      rc = (pad_rows(w - 7 + 1, 80) <= pad_rows(w - 7 + 1, 96)) ? launch_strip<128, 1, 1, 7, 80, 8>(L, in, nb, h, w, out, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 7, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      break;
+    case ((1 * 100 + 5) * 1000 + 128) * 1000 + 128:   // s_conv9
+      rc = (pad_rows(w - 5 + 1, 80) <= pad_rows(w - 5 + 1, 96)) ? launch_strip<128, 1, 1, 5, 80, 8>(L, in, nb, h, w, out, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 5, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      break;
+    case ((1 * 100 + 3) * 1000 + 128) * 1000 + 128:   // s_conv10
+      rc = (pad_rows(w - 3 + 1, 80) <= pad_rows(w - 3 + 1, 96)) ? launch_strip<128, 1, 1, 3, 80, 8>(L, in, nb, h, w, out, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 3, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      break;
+    default: return 0;
+  }
+  if (rc) return -rc;
+  return took ? 1 : 0;
+}

@@ -157,6 +157,9 @@ int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* fea
 // corr_spectral.hip
 int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
+// conv_strip.hip: LDS-resident strip kernels for the 3 x KW / stride (2,1) leg layers with 64 outputs (bf16x3 mode)
+int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, hipStream_t stream);
+
 // c3_dense.hip: c_conv3 + Flatten + Dense fused (bf16x3 mode), input patch resident in LDS
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, int n, float* partial, float* o3, hipStream_t stream);
 int ovn_dense_finish_forward(const ovn_ctx* ctx, const float* partial, int n, float* overlap, float* logit, hipStream_t stream);
