@@ -4,8 +4,8 @@
 // The generic implicit-GEMM kernel (conv_bf16x3.hip) gathers every o2 element 18 times (9 taps x 2 column blocks), splits it
 // into bf16 hi/lo each time and pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a
 // workgroup owns a band of output rows of ONE pair (22 rows = bands of 8, 7, 7): its input patch ((rows+2) x 24 pixels x 128
-// channels) is loaded and split ONCE into an LDS-resident hi/lo image (pixel stride 272 B = 17 16-byte slots: conflict-free
-// ds_read_b128 for 16 consecutive pixels), and the 3x3 taps are just address offsets into it -- no re-staging and no barrier
+// channels) is loaded and split ONCE into an LDS-resident hi/lo image (one [pixel][8 bf16] plane per group of 8 channels,
+// planes a multiple of 256 B apart: conflict-free ds_read_b128, see conv_strip.hip), and the 3x3 taps are just address offsets into it -- no re-staging and no barrier
 // in the 36-step K loop (9 taps x 4 channel chunks of 32).  The 8 waves split the 256 output channels (2 n-tiles each), every
 // wave walks all m-tiles (8 x 22 = 176 pixels = 11 exact tiles), 66 MFMAs per K step against 4 weight-fragment loads straight
 // from L2 (prefetched one step ahead).  The Dense dot product is taken in the epilogue on the accumulators (o3 never goes to
@@ -21,12 +21,13 @@ constexpr int G = OVN_G;                 // 24 input rows / cols
 constexpr int OW = OVN_O3_HW;            // 22 output rows / cols
 constexpr int CI = OVN_C2_OUT;           // 128 input channels
 constexpr int CO = OVN_C3_OUT;           // 256 output channels
-constexpr int PSTRIDE = CI + 8;          // bf16 elements per pixel in LDS (272 B)
 constexpr int NBAND = 3;                 // output-row bands per pair: [0,8) [8,15) [15,22)
 constexpr int MAX_ROWS = 8;
 constexpr int MAX_MT = (MAX_ROWS * OW + 15) / 16;          // 11 m-tiles
 constexpr int IN_PIX_MAX = (MAX_ROWS + 2) * G;             // 240 input pixels
-constexpr size_t LDS_BYTES = 2 * (size_t)IN_PIX_MAX * PSTRIDE * sizeof(__bf16) + 64;   // hi + lo images + reduction scratch
+constexpr int PLANE = IN_PIX_MAX * 8;                      // bf16 elements per 8-channel plane: [pixel][8], 3840 B = 15 x 256 B
+constexpr int NPL = CI / 8;                                // 16 planes
+constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(__bf16) + 64;   // hi + lo images + reduction scratch
 constexpr int NW = 8;
 
 __device__ __forceinline__ int band_start(int b) { return b == 0 ? 0 : (b == 1 ? 8 : 15); }
@@ -37,8 +38,8 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
                                                            float* __restrict__ partial, float* __restrict__ o3) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __bf16* ih = reinterpret_cast<__bf16*>(smem);
-  __bf16* il = ih + IN_PIX_MAX * PSTRIDE;
-  float* red = reinterpret_cast<float*>(il + IN_PIX_MAX * PSTRIDE);
+  __bf16* il = ih + NPL * PLANE;
+  float* red = reinterpret_cast<float*>(il + NPL * PLANE);
 
   const int pair = blockIdx.x / NBAND;
   const int band = blockIdx.x - pair * NBAND;
@@ -66,8 +67,9 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
         h[e] = (__bf16)v[e];
         l[e] = (__bf16)(v[e] - (float)h[e]);
       }
-      *reinterpret_cast<bf16x4*>(ih + pix * PSTRIDE + c) = h;
-      *reinterpret_cast<bf16x4*>(il + pix * PSTRIDE + c) = l;
+      const int o = (c >> 3) * PLANE + pix * 8 + (c & 7);
+      *reinterpret_cast<bf16x4*>(ih + o) = h;
+      *reinterpret_cast<bf16x4*>(il + o) = l;
     }
   }
 
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
     if (p >= npix) p = npix - 1;               // padded rows of the last tile recompute the last pixel (never stored)
     const int oy = p / OW;
     const int ox = p - oy * OW;
-    abase[mt] = (oy * G + ox) * PSTRIDE + 8 * g;
+    abase[mt] = g * PLANE + (oy * G + ox) * 8;
   }
 
   f32x4 acc[MAX_MT][2];
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   {                                                                                         \
     const int tap = (KC) >> 2;                                                              \
     const int ky = tap / 3;                                                                 \
-    const int toff = (ky * G + (tap - 3 * ky)) * PSTRIDE + 32 * ((KC) & 3);                 \
+    const int toff = (ky * G + (tap - 3 * ky)) * 8 + 4 * PLANE * ((KC) & 3);                \
     bf16x8 fh[2][2], fl[2][2];                                                              \
     C3_READ_A(0, 0, 0)                                                                      \
     C3_READ_A(0, 1, 1)                                                                      \
