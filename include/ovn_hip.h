@@ -66,7 +66,10 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1_kernel_dev, const float* 
 int ovn_finalize(ovn_ctx* ctx, int* feat_w);
 
 /* Leg: images_dev (n, in_h, in_w, in_c) -> features_dev (n, feat_w, 128).
- * Replaces `leg.predict_generator` in Infer.create_feature_volumes (infer.py:262-265). */
+ * Replaces `leg.predict_generator` in Infer.create_feature_volumes (infer.py:262-265).
+ * Every scan of one call takes the same kernels (results do not depend on the position in the batch); calls of <= 8 scans
+ * use latency-oriented split-K kernels whose summation order differs from the batched ones (equal to fp32 rounding;
+ * bit-identical across call sizes in fp32 mode, ovn_set_leg_precision(ctx, 0)). */
 int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_dev, void* stream);
 
 /* Both heads on n pairs.  Pair p uses l = feats_l_dev[lidx[p]] and r = feats_r_dev[ridx[p]]

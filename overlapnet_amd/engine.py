@@ -340,7 +340,7 @@ class OvnEngine:
         self.head_precision = mode
 
     def set_leg_precision(self, mode: str) -> None:
-        """'f32' (default) = fp32 matrix cores, 'bf16x3' = 3-term bf16 split for the leg convolutions."""
+        """'bf16x3' (default) = 3-term bf16 split on the bf16 matrix cores, 'f32' = fp32 matrix cores, for the leg convolutions."""
         table = {"f32": 0, "bf16x3": 1}
         if mode not in table:
             raise ValueError("leg precision must be one of %s" % sorted(table))
