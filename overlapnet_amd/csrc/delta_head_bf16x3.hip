@@ -129,14 +129,17 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
                                                                const __bf16* __restrict__ w1p,
                                                                const float* __restrict__ b1,
                                                                const __bf16* __restrict__ w2p,
-                                                               const float* __restrict__ b2, float* __restrict__ o2, int rot) {
+                                                               const float* __restrict__ b2, float* __restrict__ o2, int rot, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* o1h = reinterpret_cast<__bf16*>(smem_raw);
   __bf16* o1l = o1h + G * O1_STRIDE;
   float* rs = reinterpret_cast<float*>(o1l + G * O1_STRIDE);
   unsigned char* wst = reinterpret_cast<unsigned char*>(rs + 2 * S * FC);  // 2 x 24 KB window
 
-  const int pair = blockIdx.x;
+  // nsplit > 1 (small sweeps): the 12 column-group passes of a pair are spread over nsplit workgroups, so that a handful of
+  // pairs still fills the chip (a pair's latency drops from 1.4 ms to 1.4 / nsplit ms; no work is duplicated)
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
     }                                                                                                             \
   }
 
-  for (int jb2 = 0; jb2 < G / 2; ++jb2) {
+  for (int jb2 = part * (G / 2) / nsplit; jb2 < (part + 1) * (G / 2) / nsplit; ++jb2) {
     __syncthreads();  // previous pass's GEMM2 is done with o1h/o1l and rs; W window write above is visible
     for (int i4 = tid; i4 < 2 * S * FC / 4; i4 += NT_)
       *reinterpret_cast<f32x4*>(rs + 4 * i4) = *reinterpret_cast<const f32x4*>(R + jb2 * 2 * S * FC + 4 * i4);
@@ -393,9 +396,26 @@ int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const
                                  const int32_t* ridx, int n, float* o2, hipStream_t stream) {
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_bf16x3_j2_kernel<3, 8, false>), LDS_BYTES);
   if (rc) return rc;
-  hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8, false>), dim3(n), dim3(512), LDS_BYTES, stream, feats_l, lidx, feats_r,
-                     ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1, reinterpret_cast<const __bf16*>(ctx->w2p_bf),
-                     ctx->c2.bias, o2, 1);
+  // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
+  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair, W1 window and R rows set up once)
+  int nsplit = 1;
+  {
+    double best = 1e30;
+    for (const int d : {1, 2, 3, 4, 6, 12}) {
+      const double cost = (double)(((long long)n * d + 255) / 256) / d;
+      if (cost < best) best = cost;
+    }
+    for (const int d : {1, 2, 3, 4, 6, 12}) {
+      const double cost = (double)(((long long)n * d + 255) / 256) / d;
+      if (cost <= 1.05 * best) {
+        nsplit = d;
+        break;
+      }
+    }
+  }
+  hipLaunchKernelGGL((delta_c12_bf16x3_j2_kernel<3, 8, false>), dim3(n * nsplit), dim3(512), LDS_BYTES, stream, feats_l, lidx,
+                     feats_r, ridx, reinterpret_cast<const __bf16*>(ctx->w1p_bf), ctx->b1,
+                     reinterpret_cast<const __bf16*>(ctx->w2p_bf), ctx->c2.bias, o2, 1, nsplit);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

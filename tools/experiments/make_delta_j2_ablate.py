@@ -96,10 +96,10 @@ int run(const char* what, int n, const float* fl, const float* fr, const __bf16*
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1);
+  for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1, 1);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k, dim3(n), dim3(512), LDS_BYTES, 0, fl, nullptr, fr, nullptr, w1, b1, w2, b2, o2, 1, 1);
   CK(hipEventRecord(e1));
   CK(hipDeviceSynchronize());
   float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
