@@ -173,7 +173,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
   // Workgroups walk the channel slices (and with them the W1 stream) in rotated order: the 32 CUs of an XCD then
   // touch every W1 line several times per column-group period instead of in one burst, which keeps the 1 MB of
   // weights resident in the 4 MB L2 under the private L / o2 streams (LRU thrash otherwise: 18.7 GB/launch of misses).
-  const int s0 = rot ? ((blockIdx.x >> 3) & 3) : 0;
+  const int s0 = rot ? ((pair >> 3) & 3) : 0;
   const int s1 = (s0 + 1) & 3, s2 = (s0 + 2) & 3, s3 = (s0 + 3) & 3;
   OVN_LOAD_L(la, s0)
 
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_bf16x3_j2_kernel(const floa
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int t = 0; t < 3; ++t) acc2t[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int ks0 = rot ? 6 * ((blockIdx.x >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
+      const int ks0 = rot ? 6 * ((pair >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
       // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
       // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
       constexpr int GB = 3, NB = K2 / 32 / GB;

@@ -650,3 +650,15 @@ def test_gen_semantic_data_against_reference_golden(tmp_path, fixture_npz):
         diff_px = np.count_nonzero(np.any(sem[i] != want, axis=2))
         assert diff_px <= 8, "scan %d: %d pixels differ" % (i, diff_px)                 # same gate as the projection test
         assert np.array_equal(np.load(tmp_path / "dst" / "semantic" / ("%06d.npy" % i)), sem[i])
+
+
+def test_small_sweeps_equal_the_same_pairs_in_a_big_sweep(engines):
+    """Small sweeps spread a pair's 12 passes over several workgroups; same arithmetic, same result as in a big sweep."""
+    e = engines[4]
+    rng = np.random.default_rng(77)
+    fv = torch.from_numpy(np.maximum(rng.normal(0.2, 1.0, size=(300, 360, 128)), 0).astype(np.float32)).cuda()
+    q = fv[7:8].contiguous()
+    big = e.heads(fv, q, want_logit=True)
+    for n in (1, 5, 21, 100, 255):
+        small = e.heads(fv[:n].contiguous(), q, want_logit=True)
+        assert torch.equal(small["logit"], big["logit"][:n]) and torch.equal(small["yaw"], big["yaw"][:n]), n
