@@ -157,7 +157,11 @@ def _messages(r: _Reader, addr: int) -> List[Tuple[int, int, int, int]]:
         p += csz
         track_order = bool(flags & 0x04)
         blocks = [(p, chunk0)]
+        nblocks = 0
         while blocks:
+            nblocks += 1
+            if nblocks > 4096:
+                raise Hdf5Error("object header at %d: continuation chain too long (cyclic?)" % addr)
             start, size = blocks.pop(0)
             q, end = start, start + size
             while q + 4 <= end:
@@ -184,7 +188,11 @@ def _messages(r: _Reader, addr: int) -> List[Tuple[int, int, int, int]]:
     hsize = r.u(pos + 8, 4)
     blocks = [(pos + 16, hsize)]
     seen = 0
+    nblocks = 0
     while blocks and seen < nmsg:
+        nblocks += 1
+        if nblocks > 4096:
+            raise Hdf5Error("object header at %d: continuation chain too long (cyclic?)" % addr)
         start, size = blocks.pop(0)
         q, end = start, start + size
         while q + 8 <= end and seen < nmsg:
@@ -281,7 +289,7 @@ def _parse_attribute(r: _Reader, pos: int, mflags: int) -> Tuple[str, object]:
     shape = _parse_dataspace(r, spos)
     count = 0 if shape is None else (int(np.prod(shape)) if shape else 1)
     raw = r.bytes(p, count * dt.size)
-    return name.split(b"\x00")[0].decode("utf8"), _decode_values(r, dt, shape, raw)
+    return _utf8(name.split(b"\x00")[0], "an attribute name"), _decode_values(r, dt, shape, raw)
 
 
 # ----------------------------------------------------------------------------------------------------------
@@ -296,18 +304,27 @@ def _local_heap_data(r: _Reader, addr: int) -> Tuple[int, int]:
     return r.addr(data), size
 
 
+def _utf8(b: bytes, what: str) -> str:
+    try:
+        return b.decode("utf8")
+    except UnicodeDecodeError as e:
+        raise Hdf5Error("%s is not valid UTF-8 (corrupted file?)" % what) from e
+
+
 def _cstring(r: _Reader, pos: int, limit: int) -> str:
     end = r.buf.find(b"\x00", pos, pos + limit)
     if end < 0:
         raise Hdf5Error("unterminated link name in a local heap")
-    return r.buf[pos:end].decode("utf8")
+    return _utf8(r.buf[pos:end], "a link name")
 
 
 def _symtab_links(r: _Reader, btree_addr: int, heap_addr: int) -> Dict[str, int]:
     heap_pos, heap_size = _local_heap_data(r, heap_addr)
     links: Dict[str, int] = {}
 
-    def walk(addr: int) -> None:
+    def walk(addr: int, depth: int = 0) -> None:
+        if depth > 32:
+            raise Hdf5Error("group B-tree deeper than 32 levels (cyclic or corrupted)")
         pos = r.addr(addr)
         sig = r.bytes(pos, 4)
         if sig == b"TREE":
@@ -317,7 +334,7 @@ def _symtab_links(r: _Reader, btree_addr: int, heap_addr: int) -> Dict[str, int]
             p = pos + 8 + 2 * r.O
             for i in range(n):
                 p += r.L  # key i
-                walk(r.off(p))
+                walk(r.off(p), depth + 1)
                 p += r.O
         elif sig == b"SNOD":
             n = r.u(pos + 6, 2)
@@ -355,7 +372,7 @@ def _parse_link_message(r: _Reader, pos: int) -> Tuple[str, int]:
     lsz = 1 << (flags & 3)
     nlen = r.u(p, lsz)
     p += lsz
-    name = r.bytes(p, nlen).decode("utf8")
+    name = _utf8(r.bytes(p, nlen), "a link name")
     p += nlen
     if ltype != 0:
         raise Hdf5Error("soft / external link '%s' not supported" % name)
@@ -482,7 +499,9 @@ class Dataset(_Node):
             return out.tobytes()
         chunk_bytes = int(np.prod(cshape)) * esize
 
-        def walk(addr: int) -> None:
+        def walk(addr: int, depth: int = 0) -> None:
+            if depth > 32:
+                raise Hdf5Error("'%s': chunk B-tree deeper than 32 levels (cyclic or corrupted)" % self.name)
             pos = r.addr(addr)
             if r.bytes(pos, 4) != b"TREE" or r.u(pos + 4, 1) != 1:
                 raise Hdf5Error("'%s': bad chunk B-tree node at %d" % (self.name, addr))
@@ -497,7 +516,7 @@ class Dataset(_Node):
                 child = r.off(p + ksz)
                 p += ksz + r.O
                 if level > 0:
-                    walk(child)
+                    walk(child, depth + 1)
                     continue
                 raw = r.bytes(r.addr(child), csize)
                 raw = _unfilter(raw, self._filters, fmask, esize, self.name)
@@ -613,6 +632,8 @@ class Group(_Node):
             return False
 
     def __getitem__(self, path: str):
+        if not isinstance(path, str):
+            raise Hdf5Error("'%s' is a group, not a dataset (corrupted header?)" % self.name)
         node = self._file.root if path.startswith("/") else self
         for part in [p for p in path.split("/") if p]:
             if not isinstance(node, Group):

@@ -170,7 +170,7 @@ def load_keras_hdf5(path: str) -> Dict[str, np.ndarray]:
     with hdf5_lite.File(path) as f:
         root = f["model_weights"] if "model_weights" in f else f
         names = root.attrs.get("layer_names")
-        layers = [n.decode("utf8") if isinstance(n, bytes) else str(n) for n in np.asarray(names).ravel()] \
+        layers = [n.decode("utf8", "replace") if isinstance(n, bytes) else str(n) for n in np.asarray(names).ravel()] \
             if names is not None else root.keys()
         for layer in layers:
             if layer not in root:
@@ -182,7 +182,7 @@ def load_keras_hdf5(path: str) -> Dict[str, np.ndarray]:
                 grp.visititems(lambda name, obj: found.append(name) if isinstance(obj, hdf5_lite.Dataset) else None)
                 wnames = found
             for wn in np.asarray(wnames).ravel():
-                wn = wn.decode("utf8") if isinstance(wn, bytes) else str(wn)
+                wn = wn.decode("utf8", "replace") if isinstance(wn, bytes) else str(wn)
                 leaf = wn.split("/")[-1].split(":")[0]
                 if leaf in ("kernel", "bias"):
                     out["%s/%s" % (layer, leaf)] = np.ascontiguousarray(grp[wn][()], dtype=np.float32)

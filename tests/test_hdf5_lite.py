@@ -104,3 +104,34 @@ def test_full_size_model_file_written_by_h5py(tmp_path):
     W.check_weights(w, 4, {"additional_unsymmetric_layer3a": True, "strides_layer1": [2, 2]})
     for k in exp.files:
         assert np.array_equal(w[k], exp[k]), k
+
+
+def test_corrupted_files_fail_with_parser_errors_only(tmp_path):
+    """Random byte damage and truncation of the Keras-layout fixture: every failure is an Hdf5Error / KeyError / the
+    loader's own Exception -- no AttributeError, UnicodeDecodeError, IndexError, struct.error, recursion or hang."""
+    import random
+    src = open(os.path.join(G, "keras_layout_small.weight"), "rb").read()
+    rnd = random.Random(7)
+    p = tmp_path / "f.weight"
+    outcomes = {"ok": 0, "error": 0}
+    for it in range(150):
+        b = bytearray(src)
+        if it % 3 == 0:
+            for _ in range(rnd.randint(1, 8)):
+                b[rnd.randrange(len(b))] = rnd.randrange(256)
+        elif it % 3 == 1:
+            b = b[: rnd.randrange(64, len(b))]
+        else:
+            pos = rnd.randrange(0, 6000)
+            for k in range(8):
+                b[(pos + k) % len(b)] = rnd.choice([0, 255, rnd.randrange(256)])
+        p.write_bytes(bytes(b))
+        try:
+            W.load_weights_file(str(p))
+            outcomes["ok"] += 1
+        except (H.Hdf5Error, KeyError) as e:
+            outcomes["error"] += 1
+        except Exception as e:                      # the loader's own messages only
+            assert type(e) is Exception, (type(e), e)
+            outcomes["error"] += 1
+    assert outcomes["error"] > 30 and outcomes["ok"] > 0
