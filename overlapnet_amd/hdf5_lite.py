@@ -439,8 +439,11 @@ class Dataset(_Node):
         dt, shape = self._dt, self.shape
         if shape is None:
             raise Hdf5Error("'%s' has a null dataspace" % self.name)
-        count = int(np.prod(shape)) if shape else 1
+        count = int(np.prod(shape, dtype=np.float64)) if shape else 1
         nbytes = count * dt.size
+        if nbytes > max(1 << 30, 1000 * len(r.buf)):
+            raise Hdf5Error("'%s': dataspace %s needs %d bytes, implausible for a %d-byte file (corrupted header?)"
+                            % (self.name, shape, nbytes, len(r.buf)))
         pos, _ = self._layout
         ver = r.u(pos, 1)
         if ver in (1, 2):
