@@ -662,3 +662,45 @@ def test_small_sweeps_equal_the_same_pairs_in_a_big_sweep(engines):
     for n in (1, 5, 21, 100, 255):
         small = e.heads(fv[:n].contiguous(), q, want_logit=True)
         assert torch.equal(small["logit"], big["logit"][:n]) and torch.equal(small["yaw"], big["yaw"][:n]), n
+
+
+def test_100k_candidate_sweep_properties(engines):
+    """BASELINE config '1-vs-100k synthetic candidate pool' on ONE GPU (18.4 GB of feature volumes + 18.8 GB of cached spectra;
+    an 8-GPU run gives each rank an eighth of it): candidate k = query rolled by (7k mod 360) columns must come back with
+    yaw = 180 - ((180 + shift) mod 360); the 49 chunks of 2048 pairs agree with small calls on the same candidates; the
+    on-device decision equals the host argmax."""
+    import time
+    from overlapnet_amd.engine import decode_match
+    e = engines[4]
+    N = 100000
+    rng = np.random.default_rng(5)
+    q = torch.from_numpy(np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)).cuda()
+    base = torch.cat([torch.roll(q, int(s), dims=1) for s in range(360)])          # every shift once: 66 MB
+    shifts = (torch.arange(N, device="cuda") * 7) % 360
+    cands = base[shifts].contiguous()                                                # (N, 360, 128): 18.4 GB
+    del base
+    spec = e.spectrum(cands)
+    qspec = e.spectrum(q)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = e.heads(cands, q, spec_l=spec, spec_r=qspec, want_logit=True)
+    rec = e.best_match(r["overlap"], r["yaw"], 0.0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("1-vs-100k sweep on one GPU: %.3f s = %.0f pairs/s" % (dt, N / dt))
+    yaw = r["yaw"].cpu().numpy()
+    sh = shifts.cpu().numpy()
+    assert np.array_equal(yaw, 180 - ((180 + sh) % 360))
+    lg = r["logit"]
+    assert bool(torch.isfinite(lg).all())
+    # candidates with the same shift are the same scan: same logit wherever they sit in the pool, up to the position-dependent
+    # summation order of the rotated K walks (360 distinct values)
+    ref = lg[:360]
+    for lo in (360 * 100, N - N % 360 - 360):
+        assert torch.allclose(lg[lo:lo + 360], ref, rtol=2e-5, atol=2e-5)
+    for lo in (0, 2047, 2048, 51234, N - 5):                                         # chunk edges, middle, tail
+        small = e.heads(cands[lo:lo + 5].contiguous(), q, want_logit=True)["logit"]
+        assert torch.allclose(small, lg[lo:lo + 5], rtol=2e-5, atol=2e-5)
+    ov = r["overlap"].cpu().numpy()
+    k = int(np.argmax(ov))
+    assert decode_match(rec) == (k, float(ov[k]), int(yaw[k]))
