@@ -242,10 +242,13 @@ def main():
             rl_note = ("achieved counts ALGORITHMIC flops; the 3-term bf16 split issues 3 MFMA flops per algorithmic "
                        "flop, so the matrix pipe executes 3x this rate (frac <= 1/3 by construction)")
         kernels = {k: {"ms_per_launch": (v[0] / v[1] if v[1] else None), "launches": v[1]} for k, v in prof.items() if v[1]}
+        # fp32 storage and accumulation everywhere; "bf16x3" = every fp32 product as three bf16 MFMA products (x = hi + lo),
+        # ~2^-17 relative per product -- the accuracy fields below are measured in this very run against the fp64 oracle
+        dtype_label = "f32" if dtype == "f32" else "f32 (3-term bf16 split on the bf16 MFMA, fp32 accumulate)"
         out = {
             "metric": "scan-pairs/s (64x900 range images)", "value": pairs / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": {"warm": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
                                             "64x900x%d range images" % (P, P, C),
                                     "cold": "1-vs-%d sweep per GPU, COLD: %d legs from images in HBM + %d head pairs per step, "
