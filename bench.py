@@ -6,11 +6,19 @@
 
 One STEP = one loop-closure query the way the reference's `Infer.infer_multiple` runs it
 (src/two_heads/infer.py:162-203): the leg over the query scan (1 scan, 64x900xC, already in HBM) plus BOTH
-heads of that query against the P candidate feature volumes cached in HBM ("warm" sweep: candidates' legs ran
-when they were the current frame, infer.py:184-185).  N = 1, P = 1024, C = 4 is BASELINE.json configs[1]
-("batched 1-vs-1024 pairs, 64x900 depth+normals").  With N > 1 every rank holds its own P candidates
-(weak scaling, 1-vs-N*P), the only collective is the per-step gather of (overlap, yaw) to rank 0.
-Prints ONE JSON line on rank 0.
+heads of that query against the candidate feature volumes cached in HBM ("warm" sweep: candidates' legs ran
+when they were the current frame, infer.py:184-185).
+
+N = 1 (default): P = 1024 candidates, C = 4 = BASELINE.json configs[1] ("batched 1-vs-1024 pairs, 64x900 depth+normals").
+`value` is that warm sweep.  The same run then measures, each in its own timed region and reported as sub-records of the
+ONE JSON line: `fp32_mode` (every contraction on the fp32 matrix cores), `cold` (candidate legs inside the step),
+`fullstack` (raw clouds -> projection -> legs -> heads), `corr_head` (the HBM-bound correlation head alone at N = 1024 and
+16384), and the accuracy of the timed configuration over ALL pairs against the committed fp64-oracle outputs.
+
+N > 1: BASELINE.json configs[3], STRONG scaling: one 1-vs-100000 synthetic candidate pool (`--pool-total`) sharded in
+contiguous blocks over the ranks (overlapnet_amd.distributed.shard_bounds), feature volumes generated on the device
+(SURVEY.md 8d), one RCCL gather of (overlap, yaw) to rank 0 per step; value = pool_total * steps / elapsed.
+`--pool-total 0` gives the weak-scaling variant (P candidates per rank).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -32,11 +40,24 @@ from overlapnet_amd.engine import OvnEngine  # noqa: E402
 # algorithmic work of the dominant kernel (fused DeltaLayer + c_conv1 + c_conv2), SURVEY.md section 8a row a7:
 #   c_conv1 8640 x 1920 x 64 and c_conv2 576 x 960 x 128 multiply-adds per pair, FLOP = 2 * MAC
 DELTA_C12_FLOP_PER_PAIR = 2 * (8640 * 1920 * 64 + 576 * 960 * 128)
-HEAD_FLOP_PER_PAIR = 2_550_646_784          # whole Delta head
-CORR_FLOP_PER_PAIR = 33_177_600
-CAND_BYTES_PER_PAIR = 184_320 + 8           # candidate feature volume read once + (overlap, yaw) written
+CAND_BYTES_PER_PAIR = 184_320 + 8           # SURVEY.md 8d: candidate feature volume read once + (overlap, yaw) written
+SPEC_BYTES_PER_PAIR = 188_416 + 4           # what the spectral form streams: one cached spectrum (128 x 368 f32) + yaw
+LEG_FLOP_PER_SCAN = {1: 1637.5e6, 4: 1733.2e6, 5: 1765.1e6}
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
-PEAK_BF16_MFMA_TFLOPS = 2500.0              # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparse figure)
+PEAK_16BIT_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16/fp16 MFMA peak (not the 2:1-sparse figure)
+PEAK_HBM_BPS = 8.0e12
+
+HEAD_KERNEL = {
+    "f32": ("delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)", PEAK_F32_MFMA_TFLOPS, "delta_c12_kernel",
+            "fp32 matrix cores, one MFMA per product"),
+    "f16x3": ("delta_c12_f16x3_kernel (DeltaLayer+c_conv1+c_conv2, fp16 MFMA)", PEAK_16BIT_MFMA_TFLOPS, "delta_c12_f16x3",
+              "achieved counts ALGORITHMIC flops; the 3-term split issues 3 MFMA flops per algorithmic flop, so the matrix "
+              "pipe executes 3x this rate (frac <= 1/3 by construction)"),
+}
+DTYPE_LABEL = {
+    "f32": "f32",
+    "f16x3": "f32 (scaled 3-term fp16 split on the fp16 MFMA: 22 significand bits per operand, fp32 accumulate)",
+}
 
 
 def rocprof_traffic(kernel_prefix: str):
@@ -44,7 +65,7 @@ def rocprof_traffic(kernel_prefix: str):
     PMC summary under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md;
     see tools/summarize_rocprof.py) -- null if no summary names it.  Counters cannot be read live in-process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")))  # r1 < r1b < ... by name
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")), key=os.path.getmtime)
     for f in reversed(files):
         try:
             t = json.load(open(f)).get("hbm_traffic_per_launch", {})
@@ -59,7 +80,7 @@ def rocprof_traffic(kernel_prefix: str):
 def cpu_baseline(channels: int, pool: int):
     """The CPU restatement oracle (PyTorch-CPU fp32, structured like the reference: leg model, then head
     model in batches of 16 with the 360x360x128 Delta tensor materialised) timed on this host's cores on
-    a bounded sample: 1 leg + 32 pairs, extrapolated to the 1-leg + `pool`-pairs step."""
+    a bounded sample: 3 legs + 32 pairs, extrapolated to the 1-leg + `pool`-pairs step."""
     from oracle import overlapnet_oracle as O
     ncpu = os.cpu_count() or 1
     w = S.make_test_weights(channels, seed=0)
@@ -93,26 +114,78 @@ def cpu_baseline(channels: int, pool: int):
                       "1 leg + %d pairs; leg %.3f s/scan, heads %.4f s/pair" % (pool, t_leg, t_pair)}
 
 
+def timed(step, warmup, steps, eng, use_dist, dev):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks.
+    Returns (elapsed_s, per-kernel HIP-event profile, last step result)."""
+    res = None
+    for _ in range(warmup):
+        res = step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    eng.profile_begin()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_end()
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, prof, res
+
+
+def kernel_table(prof):
+    return {k: {"ms_per_launch": v[0] / v[1], "launches": v[1]} for k, v in prof.items() if v[1]}
+
+
+def golden_accuracy(ov, yw, wset="glorot"):
+    """All pairs of the sweep against the committed fp64-oracle outputs (tests/golden/make_parity_sweep_golden.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "parity_sweep_%s.npz" % wset)
+    with np.load(path) as z:
+        g = {k: z[k] for k in z.files}
+    d = np.abs(ov.astype(np.float64) - g["overlap"])
+    bad = yw != g["yaw"]
+    return {"overlap_mae_vs_oracle": float(d.mean()), "overlap_maxerr_vs_oracle": float(d.max()),
+            "overlap_p99err_vs_oracle": float(np.percentile(d, 99)),
+            "yaw_exact_rate": float(np.mean(~bad)),
+            "yaw_mismatch_max_oracle_top2_gap": float(g["corr_top2_gap"][bad].max()) if bad.any() else 0.0,
+            "accuracy_pairs": int(ov.size),
+            "accuracy_scope": "images -> leg -> heads on the GPU vs the fp64 oracle on the same images, every pair of the sweep "
+                              "(oracle outputs: tests/golden/parity_sweep_%s.npz)" % wset}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pool", type=int, default=1024, help="candidate feature volumes resident per GPU")
+    ap.add_argument("--pool", type=int, default=1024, help="candidate feature volumes resident per GPU (N = 1, or weak scaling)")
+    ap.add_argument("--pool-total", type=int, default=None,
+                    help="N > 1: size of the ONE candidate pool sharded over the ranks (default 100000 = BASELINE configs[3]); "
+                         "0 = weak scaling with --pool candidates per rank")
     ap.add_argument("--channels", type=int, default=4, help="4 = depth+normals (network.yml), 1 = depth, 5 = +intensity")
-    ap.add_argument("--head-precision", default="bf16x3", choices=["f32", "bf16x3"],
-                    help="Delta-head contraction arithmetic: fp32 MFMA, or 3-term bf16 split on the bf16 MFMA (default)")
+    ap.add_argument("--head-precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="Delta-head contraction arithmetic (fp32 storage/accumulation in both modes): scaled 3-term fp16 split "
+                         "(default) or fp32 MFMA")
+    ap.add_argument("--leg-precision", default=None, choices=["f32", "f16x3"], help="leg convolution arithmetic (default: the engine's)")
     ap.add_argument("--mode", default="warm", choices=["warm", "cold", "fullstack"],
-                    help="warm (default, the BASELINE metric): candidate features cached, step = query leg + heads; "
-                         "cold: step also runs the legs of all candidates from images resident in HBM; "
-                         "fullstack: step starts from raw point clouds (projection + normals on the GPU)")
-    ap.add_argument("--leg-precision", default="bf16x3", choices=["f32", "bf16x3"],
-                    help="leg convolution arithmetic (the Infer class defaults to f32; both are parity-tested)")
+                    help="what `value` times -- warm (default, the BASELINE metric): candidate features cached, step = query leg "
+                         "+ heads; cold: step also runs the legs of all candidates from images resident in HBM; fullstack: step "
+                         "starts from raw point clouds (projection + normals on the GPU)")
     ap.add_argument("--corr", default="spectral", choices=["spectral", "direct"],
                     help="correlation head: spectral form on cached candidate spectra (default) or direct Gram form")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (path check)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against the fp64 oracle (untimed)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32_mode / cold / fullstack / corr_head sub-records")
+    ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against a LIVE fp64 oracle when no committed "
+                                                                  "oracle outputs exist for the configuration (untimed)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,35 +203,55 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    C, P = args.channels, args.pool
+    C = args.channels
+    pool_total = args.pool_total
+    if pool_total is None:
+        pool_total = 100000 if world > 1 else 0
+    strong = pool_total > 0
+    if strong and args.mode != "warm":
+        raise SystemExit("--pool-total (one pool sharded over the ranks) is a warm sweep; use --pool-total 0 with --mode %s" % args.mode)
+    if strong:
+        lo, hi = D.shard_bounds(pool_total, world, rank)
+        P = hi - lo
+        n_total = pool_total
+    else:
+        P = args.pool
+        n_total = P * world
+
     eng = OvnEngine(64, 900, C, device=local_rank)
     w = S.make_test_weights(C, seed=0)
     eng.load_weights(w, S.REFERENCE_MODEL_CFG)
     eng.set_head_precision(args.head_precision)
-    eng.set_leg_precision(args.leg_precision)
+    if args.leg_precision:
+        eng.set_leg_precision(args.leg_precision)
+    leg_precision = eng.leg_precision
 
-    # ---- untimed setup: candidate pool -> feature volumes resident in HBM (each rank its own pool) ----
+    # ---- untimed setup: candidate pool -> feature volumes resident in HBM ----
     fx = S.load_fixture_images()
+    flags = S.flags_of(C)
     cands = torch.empty((P, 360, 128), dtype=torch.float32, device=dev)
-    cold_imgs = torch.empty((P, 64, 900, C), dtype=torch.float32, device=dev) if args.mode == "cold" else None
-    chunk = 128
-    acc_imgs = None  # host copy of the first candidates' images for the untimed end-to-end accuracy check
-    for s in range(0, P, chunk):
-        n = min(chunk, P - s)
-        imgs = S.candidate_images(n, C, seed=1234 + 7919 * rank + s, fixture=fx)
-        # distinct shifts across chunks / ranks
-        imgs = np.ascontiguousarray(np.roll(imgs, (s * 37 + rank * 11) % 900, axis=2))
-        if s == 0:
-            acc_imgs = imgs[:max(1, min(args.accuracy_pairs, n))].copy()
-        timg = torch.from_numpy(imgs).to(dev)
-        if cold_imgs is not None:
-            cold_imgs[s:s + n].copy_(timg)
-        eng.leg(timg, out=cands[s:s + n])
-    query_img = torch.from_numpy(S.stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], S.flags_of(C))[None]).to(dev)
+    pool_imgs = None
+    if strong:
+        # feature volumes generated on the device, relu(N(0.1, 1)) (~46 % zeros like leg outputs),
+        # Philox seed 1234 + rank; never 92 GB of images
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        for s in range(0, P, 4096):
+            n = min(4096, P - s)
+            cands[s:s + n] = torch.relu(torch.randn((n, 360, 128), device=dev, generator=g) + 0.1)
+    else:
+        keep_imgs = (args.mode == "cold") or (world == 1 and not args.no_extras)
+        if keep_imgs:
+            pool_imgs = torch.empty((P, 64, 900, C), dtype=torch.float32, device=dev)
+        for s, imgs in S.sweep_pool_images(P, C, rank, fx):
+            timg = torch.from_numpy(imgs).to(dev)
+            if pool_imgs is not None:
+                pool_imgs[s:s + timg.shape[0]].copy_(timg)
+            eng.leg(timg, out=cands[s:s + timg.shape[0]])
+    query_img = torch.from_numpy(S.sweep_query_image(C, fx)).to(dev)
     query_fv = torch.empty((1, 360, 128), dtype=torch.float32, device=dev)
-    raw = None
-    if args.mode == "fullstack":
-        # raw scans resident in HBM: the two shipped KITTI scans rotated about z by i * 360/P degrees
+
+    def make_raw():
+        # raw scans resident in HBM: the two shipped KITTI scans rotated about z, candidate i by (37 i mod 900) columns
         base = [torch.from_numpy(fx["points_%d" % i]).to(dev) for i in range(2)]
         pts, offs = [], [0]
         for i in range(P + 1):
@@ -170,135 +263,188 @@ def main():
             q[:, 1] = s_ * b[:, 0] + c_ * b[:, 1]
             pts.append(q)
             offs.append(offs[-1] + q.shape[0])
-        raw = (torch.cat(pts).contiguous(), torch.tensor(offs, dtype=torch.int64, device=dev), max(p.shape[0] for p in base))
-        del pts
-    flags = S.flags_of(C)
-    all_fv = torch.empty((P + 1, 360, 128), dtype=torch.float32, device=dev) if args.mode != "warm" else None
+        return (torch.cat(pts).contiguous(), torch.tensor(offs, dtype=torch.int64, device=dev), max(p.shape[0] for p in base))
+
     spectral = args.corr == "spectral"
     cand_spec = eng.spectrum(cands) if spectral else None          # cached per candidate, like its feature volume
-    query_spec = torch.empty((1, 128, eng.SPEC_W), dtype=torch.float32, device=dev) if spectral else None
+    query_spec = torch.empty((1, 128, eng.SPEC_W), dtype=torch.float32, device=dev)
+    all_fv = None
     torch.cuda.synchronize()
 
-    def step_cold():
-        if raw is not None:
-            imgs_dev = eng.project(raw[0], raw[1], raw[2], want=(), stacked_flags=flags)["stacked"]
-        else:
-            imgs_dev = torch.cat([cold_imgs, query_img])
-        eng.leg(imgs_dev, out=all_fv)
-        cf, qf = all_fv[:P], all_fv[P:]
-        if spectral:
-            sp = eng.spectrum(all_fv)
-            r = eng.heads(cf, qf, spec_l=sp[:P], spec_r=sp[P:])
-        else:
-            r = eng.heads(cf, qf)
+    def finish(r):
         if use_dist:
-            return D.gather_scores(r["overlap"], r["yaw"], P * world)
+            return D.gather_scores(r["overlap"], r["yaw"], n_total)
         return r["overlap"], r["yaw"]
 
     def step_warm():
         eng.leg(query_img, out=query_fv)
         if spectral:
             eng.spectrum(query_fv, out=query_spec)
-            r = eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec)
-        else:
-            r = eng.heads(cands, query_fv)
-        if use_dist:
-            return D.gather_scores(r["overlap"], r["yaw"], P * world)
-        return r["overlap"], r["yaw"]
+            return finish(eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec))
+        return finish(eng.heads(cands, query_fv))
 
-    step = step_warm if args.mode == "warm" else step_cold
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    eng.profile_begin()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_end()
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        pairs = P * world * args.steps
-        ms_step = 1e3 * elapsed / args.steps
-        d_ms, d_n = prof["delta_c12"]
-        avg_ms = d_ms / max(d_n, 1)
-        achieved = DELTA_C12_FLOP_PER_PAIR * P / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
-        if args.head_precision == "f32":
-            peak, kname, dtype = PEAK_F32_MFMA_TFLOPS, "delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)", "f32"
-            rl_note = "fp32 matrix cores, one MFMA per product"
-        else:
-            peak, kname, dtype = PEAK_BF16_MFMA_TFLOPS, "delta_c12_bf16x3_j2_kernel (DeltaLayer+c_conv1+c_conv2, bf16 MFMA)", "bf16x3"
-            rl_note = ("achieved counts ALGORITHMIC flops; the 3-term bf16 split issues 3 MFMA flops per algorithmic "
-                       "flop, so the matrix pipe executes 3x this rate (frac <= 1/3 by construction)")
-        kernels = {k: {"ms_per_launch": (v[0] / v[1] if v[1] else None), "launches": v[1]} for k, v in prof.items() if v[1]}
-        # fp32 storage and accumulation everywhere; "bf16x3" = every fp32 product as three bf16 MFMA products (x = hi + lo),
-        # ~2^-17 relative per product -- the accuracy fields below are measured in this very run against the fp64 oracle
-        dtype_label = "f32" if dtype == "f32" else "f32 (3-term bf16 split on the bf16 MFMA, fp32 accumulate)"
-        out = {
-            "metric": "scan-pairs/s (64x900 range images)", "value": pairs / elapsed, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
-            "config": {"workload": {"warm": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), "
-                                            "64x900x%d range images" % (P, P, C),
-                                    "cold": "1-vs-%d sweep per GPU, COLD: %d legs from images in HBM + %d head pairs per step, "
-                                            "64x900x%d" % (P, P + 1, P, C),
-                                    "fullstack": "1-vs-%d sweep per GPU from RAW scans: projection+normals of %d clouds, %d legs, "
-                                                 "%d head pairs per step, 64x900x%d" % (P, P + 1, P + 1, P, C)}[args.mode],
-                       "mode": args.mode,
-                       "pairs_per_step": P * world, "channels": C, "weights": "seeded synthetic (no trained weights ship)",
-                       "correlation_head": args.corr,
-                       "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
-            "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": rocprof_traffic("delta_c12_bf16x3" if dtype == "bf16x3" else "delta_c12_kernel"),
-                         "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * P, "avg_launch_ms": avg_ms, "note": rl_note},
-            "kernels": kernels,
-            "head_hbm_gbps_algorithmic": (P * world * args.steps / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
-        }
-        # accuracy part of the metric ("overlap MAE vs ref"): untimed check against the fp64 oracle
-        if args.accuracy_pairs > 0:
-            from oracle import overlapnet_oracle as O
-            k = min(args.accuracy_pairs, acc_imgs.shape[0])
-            ov = res[0][:k].float().cpu().numpy()
-            yw = res[1][:k].cpu().numpy()
-            # end to end: fp64 oracle leg on the same images, then fp64 heads (l = candidate, r = query)
+    def make_step_cold(raw):
+        def step_cold():
             if raw is not None:
-                # fullstack: the step started from raw clouds -> the oracle starts from the same clouds (its own
-                # projection + normals + channel stacking; fp64 trig rounded to fp32 like the HIP kernel)
-                offs = raw[1].cpu().numpy()
-                sel = list(range(k)) + [P]
-                rows = []
-                for i in sel:
-                    pts_i = raw[0][int(offs[i]):int(offs[i + 1])].cpu().numpy()
-                    rng_i, vtx_i, itn_i, _ = O.range_projection(pts_i, trig64=True)
-                    nrm_i = O.gen_normal_map(rng_i, vtx_i)
-                    rows.append(S.stack(rng_i, nrm_i, itn_i, flags))
-                all_imgs = np.stack(rows)
-                out["accuracy_scope"] = "raw clouds -> projection -> leg -> heads vs fp64 oracle (own projection)"
+                imgs_dev = eng.project(raw[0], raw[1], raw[2], want=(), stacked_flags=flags)["stacked"]
             else:
-                all_imgs = np.concatenate([acc_imgs[:k], query_img.cpu().numpy()], axis=0)
-            ofv = O.leg_forward(all_imgs, w, S.REFERENCE_MODEL_CFG, np.float64)
-            fl = ofv[:k]
-            fr = np.repeat(ofv[k:k + 1], k, axis=0)
-            o_ov, o_yaw, _, _ = O.heads_forward(fl, fr, w)
-            out.setdefault("accuracy_scope", "images -> leg -> heads vs fp64 oracle")
-            out["overlap_mae_vs_oracle"] = float(np.mean(np.abs(ov - o_ov)))
-            out["overlap_maxerr_vs_oracle"] = float(np.max(np.abs(ov - o_ov)))
-            out["yaw_exact_rate"] = float(np.mean(yw == o_yaw))
-            out["accuracy_pairs"] = int(k)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(C, P)
-        print(json.dumps(out), flush=True)
+                imgs_dev = torch.cat([pool_imgs, query_img])
+            eng.leg(imgs_dev, out=all_fv)
+            cf, qf = all_fv[:P], all_fv[P:]
+            if spectral:
+                sp = eng.spectrum(all_fv)
+                return finish(eng.heads(cf, qf, spec_l=sp[:P], spec_r=sp[P:]))
+            return finish(eng.heads(cf, qf))
+        return step_cold
+
+    raw = None
+    if args.mode != "warm":
+        all_fv = torch.empty((P + 1, 360, 128), dtype=torch.float32, device=dev)
+        raw = make_raw() if args.mode == "fullstack" else None
+        step = make_step_cold(raw)
+    else:
+        step = step_warm
+    elapsed, prof, res = timed(step, args.warmup, args.steps, eng, use_dist, dev)
+
+    if rank != 0:
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        eng.close()
+        return
+
+    pairs = n_total * args.steps
+    ms_step = 1e3 * elapsed / args.steps
+    d_ms, d_n = prof["delta_c12"]
+    avg_ms = d_ms / max(d_n, 1)
+    launch_pairs = min(P, 2048)   # the heads run in chunks of <= 2048 pairs per launch
+    if d_n:
+        # launches of one step: ceil(P / 2048) of up to 2048 pairs; the average launch carries P * steps / d_n pairs
+        launch_pairs = P * args.steps / d_n
+    achieved = DELTA_C12_FLOP_PER_PAIR * launch_pairs / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
+    kname, peak, kprefix, rl_note = HEAD_KERNEL[args.head_precision]
+    if strong:
+        workload = ("1-vs-%d synthetic candidate pool sharded over %d rank(s) in contiguous blocks (BASELINE configs[3]; warm: 1 query "
+                    "leg per rank + %d head pairs per step in total), feature volumes generated on the device, 64x900x%d query"
+                    % (n_total, world, n_total, C))
+    else:
+        workload = {"warm": "1-vs-%d candidate sweep per GPU (warm: 1 query leg + %d head pairs per step), 64x900x%d range images"
+                            % (P, P, C),
+                    "cold": "1-vs-%d sweep per GPU, COLD: %d legs from images in HBM + %d head pairs per step, 64x900x%d"
+                            % (P, P + 1, P, C),
+                    "fullstack": "1-vs-%d sweep per GPU from RAW scans: projection+normals of %d clouds, %d legs, %d head pairs per "
+                                 "step, 64x900x%d" % (P, P + 1, P + 1, P, C)}[args.mode]
+    out = {
+        "metric": "scan-pairs/s (64x900 range images)", "value": pairs / elapsed, "unit": "pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": DTYPE_LABEL[args.head_precision], "data": "synthetic",
+        "config": {"workload": workload, "mode": args.mode, "pairs_per_step": n_total, "pairs_per_rank": P, "channels": C,
+                   "weights": "seeded synthetic (no trained weights ship)", "head_precision": args.head_precision,
+                   "leg_precision": leg_precision, "correlation_head": args.corr,
+                   "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
+        "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak, "traffic": rocprof_traffic(kprefix),
+                     "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * launch_pairs, "pairs_per_launch": launch_pairs,
+                     "avg_launch_ms": avg_ms, "note": rl_note},
+        "kernels": kernel_table(prof),
+        "head_hbm_gbps_algorithmic": (pairs / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
+    }
+
+    # ---- accuracy part of the metric ("overlap MAE vs ref"), untimed ----
+    ov = res[0].float().cpu().numpy()
+    yw = res[1].cpu().numpy()
+    golden_ok = (not strong and args.mode != "fullstack" and P == 1024 and C == 4 and world == 1
+                 and os.path.isfile(os.path.join(ROOT, "tests", "golden", "parity_sweep_glorot.npz")))
+    if golden_ok:
+        out.update(golden_accuracy(ov[:P], yw[:P]))
+    elif args.accuracy_pairs > 0 and not strong:
+        from oracle import overlapnet_oracle as O
+        k = min(args.accuracy_pairs, P)
+        if raw is not None:
+            # fullstack: the step started from raw clouds -> the oracle starts from the same clouds (its own
+            # projection + normals + channel stacking; fp64 trig rounded to fp32 like the HIP kernel)
+            offs = raw[1].cpu().numpy()
+            rows = []
+            for i in list(range(k)) + [P]:
+                pts_i = raw[0][int(offs[i]):int(offs[i + 1])].cpu().numpy()
+                rng_i, vtx_i, itn_i, _ = O.range_projection(pts_i, trig64=True)
+                rows.append(S.stack(rng_i, O.gen_normal_map(rng_i, vtx_i), itn_i, flags))
+            all_imgs = np.stack(rows)
+            out["accuracy_scope"] = "raw clouds -> projection -> leg -> heads vs fp64 oracle (own projection)"
+        else:
+            first = next(S.sweep_pool_images(P, C, rank, fx))[1][:k]
+            all_imgs = np.concatenate([first, query_img.cpu().numpy()], axis=0)
+            out["accuracy_scope"] = "images -> leg -> heads vs fp64 oracle"
+        ofv = O.leg_forward(all_imgs, w, S.REFERENCE_MODEL_CFG, np.float64)
+        o_ov, o_yaw, _, _ = O.heads_forward(ofv[:k], np.repeat(ofv[k:k + 1], k, axis=0), w)
+        out["overlap_mae_vs_oracle"] = float(np.mean(np.abs(ov[:k] - o_ov)))
+        out["overlap_maxerr_vs_oracle"] = float(np.max(np.abs(ov[:k] - o_ov)))
+        out["yaw_exact_rate"] = float(np.mean(yw[:k] == o_yaw))
+        out["accuracy_pairs"] = int(k)
+
+    # ---- sub-records: every other number DESIGN.md quotes, measured in this same run (N = 1 only) ----
+    if world == 1 and not strong and not args.no_extras and args.mode == "warm":
+        sub_steps = max(args.steps, 20)
+        # (1) everything on the fp32 matrix cores, direct correlation form
+        eng.set_head_precision("f32")
+        eng.set_leg_precision("f32")
+
+        def step_f32():
+            eng.leg(query_img, out=query_fv)
+            r = eng.heads(cands_f32, query_fv)
+            return r["overlap"], r["yaw"]
+        cands_f32 = torch.empty_like(cands)
+        for s in range(0, P, 128):
+            eng.leg(pool_imgs[s:s + 128], out=cands_f32[s:s + 128])
+        e2, p2, r2 = timed(step_f32, 2, 5, eng, False, dev)
+        rec = {"value": P * 5 / e2, "unit": "pairs/s", "ms_per_step": 1e3 * e2 / 5, "steps": 5,
+               "arithmetic": "leg + Delta head + direct correlation head on v_mfma_f32_16x16x4_f32 (bit-for-bit an fp32 FMA chain)",
+               "delta_c12_ms": p2["delta_c12"][0] / max(p2["delta_c12"][1], 1)}
+        if golden_ok:
+            ga = golden_accuracy(r2[0].float().cpu().numpy(), r2[1].cpu().numpy())
+            rec.update({k: ga[k] for k in ("overlap_mae_vs_oracle", "overlap_maxerr_vs_oracle", "yaw_exact_rate", "accuracy_pairs")})
+        out["fp32_mode"] = rec
+        del cands_f32
+        eng.set_head_precision(args.head_precision)
+        eng.set_leg_precision(leg_precision)
+        # (2) cold: the legs of all candidates inside the step
+        all_fv = torch.empty((P + 1, 360, 128), dtype=torch.float32, device=dev)
+        e3, p3, r3 = timed(make_step_cold(None), 2, sub_steps, eng, False, dev)
+        leg_ms = p3["leg_conv"][0] / sub_steps
+        out["cold"] = {"value": P * sub_steps / e3, "unit": "pairs/s", "ms_per_step": 1e3 * e3 / sub_steps, "steps": sub_steps,
+                       "step": "%d legs from images in HBM + spectra + %d head pairs" % (P + 1, P), "leg_ms_per_step": leg_ms,
+                       "leg_scans_per_s": (P + 1) / (leg_ms * 1e-3),
+                       "leg_frac_of_16bit_mfma_peak_algorithmic": (P + 1) * LEG_FLOP_PER_SCAN.get(C, 1733.2e6) / (leg_ms * 1e-3) / 1e12
+                       / PEAK_16BIT_MFMA_TFLOPS}
+        # (3) fullstack: raw clouds -> projection + normals -> legs -> heads
+        raw2 = make_raw()
+        e4, p4, r4 = timed(make_step_cold(raw2), 2, sub_steps, eng, False, dev)
+        out["fullstack"] = {"value": P * sub_steps / e4, "unit": "pairs/s", "ms_per_step": 1e3 * e4 / sub_steps, "steps": sub_steps,
+                            "step": "projection + normals of %d raw clouds, %d legs, spectra, %d head pairs" % (P + 1, P + 1, P),
+                            "projection_ms_per_step": p4["projection"][0] / sub_steps,
+                            "projection_scans_per_s": (P + 1) / (p4["projection"][0] / sub_steps * 1e-3)}
+        del raw2, all_fv
+        # (4) the correlation head alone (the kernel the north star puts an HBM-roofline number on), N = 1024 and 16384
+        ch = {}
+        for n_c in (1024, 16384):
+            gen = torch.Generator(device=dev).manual_seed(99)
+            f = cands if n_c == P else torch.relu(torch.randn((n_c, 360, 128), device=dev, generator=gen) + 0.1)
+            sp = cand_spec if n_c == P else eng.spectrum(f)
+            qs = eng.spectrum(query_fv)
+            e5, p5, _ = timed(lambda: eng.corr_head_spectral(sp, qs), 3, sub_steps, eng, False, dev)
+            ms = p5["corr_spectral"][0] / p5["corr_spectral"][1]
+            ch["n%d" % n_c] = {"ms": ms, "pairs_per_s": n_c / (ms * 1e-3),
+                               "algorithmic_bytes": n_c * CAND_BYTES_PER_PAIR, "streamed_bytes": n_c * SPEC_BYTES_PER_PAIR,
+                               "frac_of_8TBps": n_c * CAND_BYTES_PER_PAIR / (ms * 1e-3) / PEAK_HBM_BPS,
+                               "frac_of_8TBps_streamed": n_c * SPEC_BYTES_PER_PAIR / (ms * 1e-3) / PEAK_HBM_BPS}
+            del f, sp
+        ch["note"] = ("spectral form on cached candidate spectra; `frac_of_8TBps` prices SURVEY.md 8d's algorithmic bytes (184,328 B per "
+                      "pair), `..._streamed` the 188,420 B the kernel actually reads and writes per pair; ms = HIP events around the launch(es)")
+        out["corr_head"] = ch
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(C, P)
+    print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,10 +1,10 @@
 // c_conv3 (3x3, 128 -> 256, ReLU) + Flatten + Dense(1) fused, input patch resident in LDS, for gfx950.
 //
 // Reference: generateNet.py:108-114 (Conv2D(256,(3,3),relu) -> Flatten -> Dense(1, sigmoid)).
-// The generic implicit-GEMM kernel (conv_bf16x3.hip) gathers every o2 element 18 times (9 taps x 2 column blocks), splits it
-// into bf16 hi/lo each time and pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a
+// The generic implicit-GEMM kernel (conv_f16x3.hip) gathers every o2 element 18 times (9 taps x 2 column blocks), splits it
+// into hi/lo halves each time and pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a
 // workgroup owns a band of output rows of ONE pair (22 rows = bands of 8, 7, 7): its input patch ((rows+2) x 24 pixels x 128
-// channels) is loaded and split ONCE into an LDS-resident hi/lo image (one [pixel][8 bf16] plane per group of 8 channels,
+// channels) is loaded and split ONCE into an LDS-resident hi/lo image (one [pixel][8 fp16] plane per group of 8 channels,
 // planes a multiple of 256 B apart: conflict-free ds_read_b128, see conv_strip.hip), and the 3x3 taps are just address offsets into it -- no re-staging and no barrier
 // in the 36-step K loop (9 taps x 4 channel chunks of 32).  The 8 waves split the 256 output channels (2 n-tiles each), every
 // wave walks all m-tiles (8 x 22 = 176 pixels = 11 exact tiles), 66 MFMAs per K step against 4 weight-fragment loads straight
@@ -12,10 +12,18 @@
 // HBM unless asked for): per-band partial sums, combined in a fixed order by dense_finish_kernel (deterministic).
 #include "ovn_internal.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+// scaled fp16 hi/lo arithmetic ("f16x3", see delta_head_f16x3.hip)
+struct ArithF16 {
+  typedef _Float16 elem;
+  typedef f16x8 v8;
+  typedef f16x4 v4;
+  static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
 
 constexpr int G = OVN_G;                 // 24 input rows / cols
 constexpr int OW = OVN_O3_HW;            // 22 output rows / cols
@@ -25,20 +33,28 @@ constexpr int NBAND = 3;                 // output-row bands per pair: [0,8) [8,
 constexpr int MAX_ROWS = 8;
 constexpr int MAX_MT = (MAX_ROWS * OW + 15) / 16;          // 11 m-tiles
 constexpr int IN_PIX_MAX = (MAX_ROWS + 2) * G;             // 240 input pixels
-constexpr int PLANE = IN_PIX_MAX * 8;                      // bf16 elements per 8-channel plane: [pixel][8], 3840 B = 15 x 256 B
+constexpr int PLANE = IN_PIX_MAX * 8;                      // fp16 elements per 8-channel plane: [pixel][8], 3840 B = 15 x 256 B
 constexpr int NPL = CI / 8;                                // 16 planes
-constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(__bf16) + 64;   // hi + lo images + reduction scratch
+constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 64;   // hi + lo images + reduction scratch
 constexpr int NW = 8;
 
 __device__ __forceinline__ int band_start(int b) { return b == 0 ? 0 : (b == 1 ? 8 : 15); }
 __device__ __forceinline__ int band_rows(int b) { return b == 0 ? 8 : 7; }
 
-__global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restrict__ o2, const __bf16* __restrict__ wp,
+// `o2max` (n) holds the float bits of each pair's max o2 value (written by the Delta kernel's epilogue); the patch is scaled by
+// s2 = 2^14 / 2^ceil(log2 max) before the split, the weights were scaled by `sw3` when they were registered, and the
+// accumulators are divided by s2 * sw3 (powers of two: exact).
+template <class A>
+__global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restrict__ o2, const typename A::elem* __restrict__ wp,
                                                            const float* __restrict__ b3, const float* __restrict__ wd,
+                                                           const unsigned* __restrict__ o2max, float sw3,
                                                            float* __restrict__ partial, float* __restrict__ o3) {
+  typedef typename A::elem elem_t;
+  typedef typename A::v8 v8_t;
+  typedef typename A::v4 v4_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __bf16* ih = reinterpret_cast<__bf16*>(smem);
-  __bf16* il = ih + NPL * PLANE;
+  elem_t* ih = reinterpret_cast<elem_t*>(smem);
+  elem_t* il = ih + NPL * PLANE;
   float* red = reinterpret_cast<float*>(il + NPL * PLANE);
 
   const int pair = blockIdx.x / NBAND;
@@ -53,7 +69,9 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   const int lrow = lane & 15;
   const int g = lane >> 4;
 
-  // ---- input patch -> LDS, split once (x = hi + lo, both bf16, round to nearest) ----
+  const float s2 = ovn_pow2_scale_for(__uint_as_float(o2max[pair]));
+  const float inv = 1.0f / (s2 * sw3);
+  // ---- input patch -> LDS, split once (x * s2 = hi + lo, both 16-bit, round to nearest) ----
   {
     const float* src = o2 + ((long long)pair * G + r0) * G * CI;     // rows r0 .. r0 + nrows + 1, contiguous in NHWC
     const int n4 = (nrows + 2) * G * CI / 4;
@@ -61,15 +79,16 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
       const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
       const int pix = i / (CI / 4);
       const int c = 4 * (i - pix * (CI / 4));
-      bf16x4 h, l;
+      v4_t h, l;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        h[e] = (__bf16)v[e];
-        l[e] = (__bf16)(v[e] - (float)h[e]);
+        const float x = v[e] * s2;
+        h[e] = (elem_t)x;
+        l[e] = (elem_t)(x - (float)h[e]);
       }
       const int o = (c >> 3) * PLANE + pix * 8 + (c & 7);
-      *reinterpret_cast<bf16x4*>(ih + o) = h;
-      *reinterpret_cast<bf16x4*>(il + o) = l;
+      *reinterpret_cast<v4_t*>(ih + o) = h;
+      *reinterpret_cast<v4_t*>(il + o) = l;
     }
   }
 
@@ -92,40 +111,40 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   }
 
   // weight fragments: wp[kc][nt(16)][hi,lo][lane][8], kc = tap * 4 + channel chunk; this wave's n-tiles 2w, 2w+1
-  const __bf16* wsrc = wp + ((size_t)(2 * wave) * 2) * 512 + lane * 8;
-  bf16x8 bq[3][4];   // weight fragments of three K steps in flight (an L2 round trip is longer than one step)
+  const elem_t* wsrc = wp + ((size_t)(2 * wave) * 2) * 512 + lane * 8;
+  v8_t bq[3][4];   // weight fragments of three K steps in flight (an L2 round trip is longer than one step)
 #define C3_LOAD_B(DST, KC)                                                                  \
   {                                                                                         \
-    const __bf16* q = wsrc + (size_t)(KC) * (16 * 2 * 512);                                 \
-    DST[0] = *reinterpret_cast<const bf16x8*>(q);                                           \
-    DST[1] = *reinterpret_cast<const bf16x8*>(q + 512);                                     \
-    DST[2] = *reinterpret_cast<const bf16x8*>(q + 1024);                                    \
-    DST[3] = *reinterpret_cast<const bf16x8*>(q + 1536);                                    \
+    const elem_t* q = wsrc + (size_t)(KC) * (16 * 2 * 512);                                 \
+    DST[0] = *reinterpret_cast<const v8_t*>(q);                                           \
+    DST[1] = *reinterpret_cast<const v8_t*>(q + 512);                                     \
+    DST[2] = *reinterpret_cast<const v8_t*>(q + 1024);                                    \
+    DST[3] = *reinterpret_cast<const v8_t*>(q + 1536);                                    \
   }
 // m-tiles go two at a time and term-major, so that consecutive MFMAs never chain on one accumulator (4 apart)
 #define C3_MFMA2(M0, M1, A0H, A0L, A1H, A1L, SRC)                                                  \
-  acc[M0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[0], acc[M0][0], 0, 0, 0);          \
-  acc[M0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[2], acc[M0][1], 0, 0, 0);          \
-  acc[M1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[0], acc[M1][0], 0, 0, 0);          \
-  acc[M1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[2], acc[M1][1], 0, 0, 0);          \
-  acc[M0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0L, SRC[0], acc[M0][0], 0, 0, 0);          \
-  acc[M0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0L, SRC[2], acc[M0][1], 0, 0, 0);          \
-  acc[M1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1L, SRC[0], acc[M1][0], 0, 0, 0);          \
-  acc[M1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1L, SRC[2], acc[M1][1], 0, 0, 0);          \
-  acc[M0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[1], acc[M0][0], 0, 0, 0);          \
-  acc[M0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0H, SRC[3], acc[M0][1], 0, 0, 0);          \
-  acc[M1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[1], acc[M1][0], 0, 0, 0);          \
-  acc[M1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1H, SRC[3], acc[M1][1], 0, 0, 0);
+  acc[M0][0] = A::mfma(A0H, SRC[0], acc[M0][0]);          \
+  acc[M0][1] = A::mfma(A0H, SRC[2], acc[M0][1]);          \
+  acc[M1][0] = A::mfma(A1H, SRC[0], acc[M1][0]);          \
+  acc[M1][1] = A::mfma(A1H, SRC[2], acc[M1][1]);          \
+  acc[M0][0] = A::mfma(A0L, SRC[0], acc[M0][0]);          \
+  acc[M0][1] = A::mfma(A0L, SRC[2], acc[M0][1]);          \
+  acc[M1][0] = A::mfma(A1L, SRC[0], acc[M1][0]);          \
+  acc[M1][1] = A::mfma(A1L, SRC[2], acc[M1][1]);          \
+  acc[M0][0] = A::mfma(A0H, SRC[1], acc[M0][0]);          \
+  acc[M0][1] = A::mfma(A0H, SRC[3], acc[M0][1]);          \
+  acc[M1][0] = A::mfma(A1H, SRC[1], acc[M1][0]);          \
+  acc[M1][1] = A::mfma(A1H, SRC[3], acc[M1][1]);
 // A fragments are read one tile pair ahead of the MFMAs that consume them (the LDS round trip hides behind 12 MFMAs)
 #define C3_READ_A(BUF, SLOT, MT)                                                            \
-  fh[BUF][SLOT] = *reinterpret_cast<const bf16x8*>(ih + abase[MT] + toff);                  \
-  fl[BUF][SLOT] = *reinterpret_cast<const bf16x8*>(il + abase[MT] + toff);
+  fh[BUF][SLOT] = *reinterpret_cast<const v8_t*>(ih + abase[MT] + toff);                  \
+  fl[BUF][SLOT] = *reinterpret_cast<const v8_t*>(il + abase[MT] + toff);
 #define C3_STEP(SRC, KC)                                                                    \
   {                                                                                         \
     const int tap = (KC) >> 2;                                                              \
     const int ky = tap / 3;                                                                 \
     const int toff = (ky * G + (tap - 3 * ky)) * 8 + 4 * PLANE * ((KC) & 3);                \
-    bf16x8 fh[2][2], fl[2][2];                                                              \
+    v8_t fh[2][2], fl[2][2];                                                              \
     C3_READ_A(0, 0, 0)                                                                      \
     C3_READ_A(0, 1, 1)                                                                      \
     _Pragma("unroll") for (int q = 0; q < MAX_MT / 2; ++q) {                                \
@@ -141,13 +160,13 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
       __builtin_amdgcn_sched_barrier(0);                                                    \
     }                                                                                       \
     if (nmt == MAX_MT) {  /* the 8-row band has an 11th tile */                             \
-      const bf16x8 ah = fh[(MAX_MT / 2) & 1][0], al = fl[(MAX_MT / 2) & 1][0];              \
-      acc[MAX_MT - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[0], acc[MAX_MT - 1][0], 0, 0, 0); \
-      acc[MAX_MT - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[2], acc[MAX_MT - 1][1], 0, 0, 0); \
-      acc[MAX_MT - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, SRC[0], acc[MAX_MT - 1][0], 0, 0, 0); \
-      acc[MAX_MT - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, SRC[2], acc[MAX_MT - 1][1], 0, 0, 0); \
-      acc[MAX_MT - 1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[1], acc[MAX_MT - 1][0], 0, 0, 0); \
-      acc[MAX_MT - 1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, SRC[3], acc[MAX_MT - 1][1], 0, 0, 0); \
+      const v8_t ah = fh[(MAX_MT / 2) & 1][0], al = fl[(MAX_MT / 2) & 1][0];              \
+      acc[MAX_MT - 1][0] = A::mfma(ah, SRC[0], acc[MAX_MT - 1][0]); \
+      acc[MAX_MT - 1][1] = A::mfma(ah, SRC[2], acc[MAX_MT - 1][1]); \
+      acc[MAX_MT - 1][0] = A::mfma(al, SRC[0], acc[MAX_MT - 1][0]); \
+      acc[MAX_MT - 1][1] = A::mfma(al, SRC[2], acc[MAX_MT - 1][1]); \
+      acc[MAX_MT - 1][0] = A::mfma(ah, SRC[1], acc[MAX_MT - 1][0]); \
+      acc[MAX_MT - 1][1] = A::mfma(ah, SRC[3], acc[MAX_MT - 1][1]); \
     }                                                                                       \
   }
   C3_LOAD_B(bq[0], 0)
@@ -179,7 +198,7 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
       for (int r = 0; r < 4; ++r) {
         const int p = 16 * mt + 4 * g + r;
         if (p < npix) {
-          const float v = fmaxf(acc[mt][nt][r] + bv, 0.0f);
+          const float v = fmaxf(fmaf(acc[mt][nt][r], inv, bv), 0.0f);
           const long long fi = (long long)(r0 * OW + p) * CO + n;     // Flatten index (H, W, C) of this value
           s += v * wd[fi];
           if (o3) o3[(long long)pair * OVN_DENSE_IN + fi] = v;
@@ -209,11 +228,13 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
 
 // o2 (n,24,24,128) fp32 -> partial (3 n) Dense partial sums per output-row band [+ o3 (n,22,22,256) when not NULL];
 // ovn_dense_finish_forward turns the partials into logit / overlap.
-int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, int n, float* partial, float* o3, hipStream_t stream) {
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel), LDS_BYTES);
+int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
+                         hipStream_t stream) {
+  OVN_REQUIRE(o2max != nullptr, OVN_ERR_ARG, "ovn_c3_dense_forward: the per-pair maxima of o2 are required");
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16>), LDS_BYTES);
   if (rc) return rc;
-  hipLaunchKernelGGL(c3_dense_kernel, dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
-                     reinterpret_cast<const __bf16*>(ctx->c3.wp_bf), ctx->c3.bias, ctx->wd, partial, o3);
+  hipLaunchKernelGGL(c3_dense_kernel<ArithF16>, dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
+                     reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

@@ -1,46 +1,64 @@
-// Valid-padded NHWC convolution + bias (+ReLU) as an implicit GEMM on the bf16 matrix cores with the 3-term
-// split (x = hi + lo in bf16, a*w ~ ah*wh + al*wh + ah*wl, fp32 accumulate) for gfx950.
+// Valid-padded NHWC convolution + bias (+ReLU) as an implicit GEMM on the fp16 matrix cores with the scaled 3-term
+// split ("f16x3": s x = hi + lo in fp16 with a power-of-two scale s, a*w ~ ah*wh + al*wh + ah*wl, fp32 accumulate:
+// 22 significand bits per operand, the error of an fp32 evaluation -- see delta_head_f16x3.hip) for gfx950.
 //
 // Same contract, GEMM view and gather scheme as conv_f32.hip (reference: Keras Conv2D(padding='valid'),
-// generateNet.py:108-110 for c_conv3, :161-214 for the leg); used where fp32 matrix-core time dominates.
-// The K loop advances 32 at a time (one v_mfma_f32_16x16x32_bf16 step).  A-tile values are split into hi/lo
-// bf16 ONCE when they are staged into LDS (8 values per thread per chunk, amortised over all Cout columns);
-// weights are split and laid out in fragment order when the layer is registered.
+// generateNet.py:161-214 for the leg); used where fp32 matrix-core time dominates.
+// The K loop advances 32 at a time (one v_mfma_f32_16x16x32_f16 step).  A-tile values are scaled and split into hi/lo
+// fp16 ONCE when they are staged into LDS (8 values per thread per chunk, amortised over all Cout columns);
+// weights are scaled, split and laid out in fragment order when the layer is registered.
+// Scales: the weights' is static (max |W| -> 2^14); the activations' comes from `in_max`, the float bits of the largest
+// |input| of the call, which the PRODUCER of the tensor leaves in device memory (every kernel here folds its outputs into
+// `out_max` with one atomicMax per wave; the first layer's input is scanned by ovn_absmax_forward) -- no host round trip.
 #include <stdlib.h>
 
 #include "ovn_internal.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
 constexpr int KC = 32;          // K elements per chunk
-constexpr int A_STRIDE = 40;    // bf16 elements per A row in LDS (32 + 8 pad: 80 B = 5 slots, odd -> no conflicts)
+constexpr int A_STRIDE = 40;    // fp16 elements per A row in LDS (32 + 8 pad: 80 B = 5 slots, odd -> no conflicts)
 
 struct ConvArgsB {
   const float* in;
-  const __bf16* wp;   // [nkc][Cout/16][hi,lo][64][8]
+  const _Float16* wp;   // [nkc][Cout/16][hi,lo][64][8], scaled by sw
   const float* bias;
   float* out;
+  const unsigned* in_max;   // float bits of max |input| (device), written by the producer of `in`
+  unsigned* out_max;        // NULL, or where this layer folds max |output| (atomicMax on the float bits)
+  float sw;                 // power-of-two scale of wp
   int H, W, Cin, OH, OW, Cout, SH, SW;
   int K, nkc, KWC, rowstride;
   long long M;
   int relu;
 };
 
-__device__ __forceinline__ void split_pair_rne(float d0, float d1, unsigned& hi_pk, unsigned& lo_pk) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 h, l;
-  h[0] = (__bf16)d0;
-  h[1] = (__bf16)d1;
-  l[0] = (__bf16)(d0 - (float)h[0]);
-  l[1] = (__bf16)(d1 - (float)h[1]);
+// (s d0, s d1) -> hi, lo as packed fp16 pairs.  hi = fp16_rtz (v_cvt_pkrtz_f16_f32: one instruction per pair), lo = fp16_rne of the
+// exact remainder, through v_fma_mixlo/hi_f16 (`one` = 1.0f in a register keeps the compiler from folding the fma into a subtraction
+// that needs two more conversions, see delta_head_f16x3.hip).
+__device__ __forceinline__ void split_pair_f16(float d0, float d1, float s, float one, unsigned& hi_pk, unsigned& lo_pk) {
+  const float x0 = d0 * s, x1 = d1 * s;
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  f16x2 l;
+  l[0] = (_Float16)__builtin_fmaf(x0, one, -(float)h[0]);
+  l[1] = (_Float16)__builtin_fmaf(x1, one, -(float)h[1]);
   hi_pk = __builtin_bit_cast(unsigned, h);
   lo_pk = __builtin_bit_cast(unsigned, l);
 }
 
-__global__ void conv_prep_bf16_kernel(const float* __restrict__ w, __bf16* __restrict__ wp, int K, int nkc, int Cout) {
+// max |output| of a wave -> one atomicMax (|v| orders like its float bits)
+__device__ __forceinline__ void fold_absmax(float vmax, unsigned* out_max) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(out_max, __float_as_uint(vmax));
+}
+
+// Scaled fp16 hi/lo fragments (f16x3 arithmetic), same fragment order: sw * W = hi + lo, both rounded to nearest.
+__global__ void conv_prep_f16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int K, int nkc, int Cout, float sw) {
   const int NT = Cout / 16;
   const long long total = (long long)nkc * NT * 512;  // (hi, lo) pairs
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total;
@@ -52,24 +70,39 @@ __global__ void conv_prep_bf16_kernel(const float* __restrict__ w, __bf16* __res
     const int kc = (int)(t / NT);
     const int k = kc * KC + 8 * (lane >> 4) + s;
     const int n = nt * 16 + (lane & 15);
-    const float v = (k < K) ? w[(long long)k * Cout + n] : 0.0f;
-    const __bf16 hi = (__bf16)v;
-    const __bf16 lo = (__bf16)(v - (float)hi);
+    const float v = (k < K) ? sw * w[(long long)k * Cout + n] : 0.0f;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
     const long long base = (((long long)kc * NT + nt) * 2) * 512 + lane * 8 + s;
     wp[base] = hi;
     wp[base + 512] = lo;
   }
 }
 
+// out[0] = max |w[i]|, i < n; one workgroup
+__global__ __launch_bounds__(1024) void conv_absmax_kernel(const float* __restrict__ w, long long n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float m = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) m = fmaxf(m, red[i]);
+    out[0] = m;
+  }
+}
+
 // The tiles are passed as __restrict__ pointers so that the compiler keeps treating the three LDS regions as
 // disjoint when they are carved out of one dynamic allocation (without it the ds_write/ds_read streams serialise).
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
-__device__ __forceinline__ void conv_mfma_bf16x3_body(const ConvArgsB& a, __bf16* __restrict__ Ah, __bf16* __restrict__ Al,
+__device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float one, _Float16* __restrict__ Ah, _Float16* __restrict__ Al,
                                                       unsigned char* __restrict__ Bs) {
   constexpr int NTHREADS = 64 * WAVES_M * WAVES_N;
   constexpr int BM = 16 * WM * WAVES_M;
   constexpr int BN = 16 * WN * WAVES_N;
-  constexpr int ATILE = BM * A_STRIDE;   // bf16 elements per A buffer
+  constexpr int ATILE = BM * A_STRIDE;   // fp16 elements per A buffer
   constexpr int BTILE = BN * 128;        // bytes per B buffer
   constexpr int A_SLOTS = (BM * 4) / NTHREADS;                 // 8-float slots of A per thread per chunk
   constexpr int B_VEC = BN * 8;                                // 16-byte slots of B per chunk (hi + lo)
@@ -88,6 +121,8 @@ __device__ __forceinline__ void conv_mfma_bf16x3_body(const ConvArgsB& a, __bf16
   const long long m0 = (long long)blockIdx.x * BM;
   const int nt0 = blockIdx.y * (BN / 16);
   const int NT = a.Cout / 16;
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
+  const float inv = 1.0f / (s_in * a.sw);
 
   long long abase[A_SLOTS];
 #pragma unroll
@@ -173,10 +208,10 @@ __device__ __forceinline__ void conv_mfma_bf16x3_body(const ConvArgsB& a, __bf16
     for (int r = 0; r < A_SLOTS; ++r) {
       const int slot = tid + r * NTHREADS;
       unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-      split_pair_rne(areg[r][0][0], areg[r][0][1], h0, l0);
-      split_pair_rne(areg[r][0][2], areg[r][0][3], h1, l1);
-      split_pair_rne(areg[r][1][0], areg[r][1][1], h2, l2);
-      split_pair_rne(areg[r][1][2], areg[r][1][3], h3, l3);
+      split_pair_f16(areg[r][0][0], areg[r][0][1], s_in, one, h0, l0);
+      split_pair_f16(areg[r][0][2], areg[r][0][3], s_in, one, h1, l1);
+      split_pair_f16(areg[r][1][0], areg[r][1][1], s_in, one, h2, l2);
+      split_pair_f16(areg[r][1][2], areg[r][1][3], s_in, one, h3, l3);
       const int off = (slot >> 2) * A_STRIDE + 8 * (slot & 3);
       *reinterpret_cast<u32x4*>(&Ah[buf * ATILE + off]) = (u32x4){h0, h1, h2, h3};
       *reinterpret_cast<u32x4*>(&Al[buf * ATILE + off]) = (u32x4){l0, l1, l2, l3};
@@ -203,38 +238,39 @@ __device__ __forceinline__ void conv_mfma_bf16x3_body(const ConvArgsB& a, __bf16
     const bool more = (kc + 1 < a.nkc);
     if (more) load_chunk(kc + 1);
 
-    bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+    f16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       const int off = ((wave_m * WM + i) * 16 + lrow) * A_STRIDE + 8 * g;
-      ah[i] = *reinterpret_cast<const bf16x8*>(&Ah[cur * ATILE + off]);
-      al[i] = *reinterpret_cast<const bf16x8*>(&Al[cur * ATILE + off]);
+      ah[i] = *reinterpret_cast<const f16x8*>(&Ah[cur * ATILE + off]);
+      al[i] = *reinterpret_cast<const f16x8*>(&Al[cur * ATILE + off]);
     }
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int off = (((wave_n * WN + j) * 2) * 64 + lane) * 16;
-      bh[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BTILE + off]);
-      bl[j] = *reinterpret_cast<const bf16x8*>(&Bs[cur * BTILE + off + 1024]);
+      bh[j] = *reinterpret_cast<const f16x8*>(&Bs[cur * BTILE + off]);
+      bl[j] = *reinterpret_cast<const f16x8*>(&Bs[cur * BTILE + off + 1024]);
     }
     // term-major so that consecutive MFMAs never chain on the same accumulator
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
-      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 
     if (more) store_chunk(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
 
+  float vmax = 0.f;
 #pragma unroll
   for (int j = 0; j < WN; ++j) {
     const int n = (nt0 + wave_n * WN + j) * 16 + lrow;
@@ -245,34 +281,36 @@ __device__ __forceinline__ void conv_mfma_bf16x3_body(const ConvArgsB& a, __bf16
       for (int r = 0; r < 4; ++r) {
         const long long m = m0 + (wave_m * WM + i) * 16 + 4 * g + r;
         if (m < a.M) {
-          float v = acc[i][j][r] + bv;
+          float v = fmaf(acc[i][j][r], inv, bv);
           if (a.relu) v = fmaxf(v, 0.0f);
           a.out[m * a.Cout + n] = v;
+          vmax = fmaxf(vmax, fabsf(v));
         }
       }
     }
   }
+  if (a.out_max) fold_absmax(vmax, a.out_max);
 }
 
 // static LDS (<= 64 KB): the common tiles
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_kernel(ConvArgsB a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_f16x3_kernel(ConvArgsB a, float one) {
   constexpr int BM = 16 * WM * WAVES_M;
   constexpr int BN = 16 * WN * WAVES_N;
-  __shared__ __attribute__((aligned(16))) __bf16 Ah[2 * BM * A_STRIDE];
-  __shared__ __attribute__((aligned(16))) __bf16 Al[2 * BM * A_STRIDE];
+  __shared__ __attribute__((aligned(16))) _Float16 Ah[2 * BM * A_STRIDE];
+  __shared__ __attribute__((aligned(16))) _Float16 Al[2 * BM * A_STRIDE];
   __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * BN * 128];
-  conv_mfma_bf16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, Ah, Al, Bs);
+  conv_mfma_f16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, one, Ah, Al, Bs);
 }
 
 // dynamic LDS: [Ah 2 x BM x A_STRIDE][Al same][Bs 2 x BN x 128 B] (the 128 x 128 tile needs 72 KB > the 64 KB static limit)
 template <int WM, int WN, int WAVES_M, int WAVES_N, bool VEC4>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_dyn_kernel(ConvArgsB a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_f16x3_dyn_kernel(ConvArgsB a, float one) {
   constexpr int BM = 16 * WM * WAVES_M;
   extern __shared__ __attribute__((aligned(16))) unsigned char conv_smem[];
-  conv_mfma_bf16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, reinterpret_cast<__bf16*>(conv_smem),
-                                                        reinterpret_cast<__bf16*>(conv_smem) + 2 * BM * A_STRIDE,
-                                                        conv_smem + 4 * BM * A_STRIDE * sizeof(__bf16));
+  conv_mfma_f16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, one, reinterpret_cast<_Float16*>(conv_smem),
+                                                       reinterpret_cast<_Float16*>(conv_smem) + 2 * BM * A_STRIDE,
+                                                       conv_smem + 4 * BM * A_STRIDE * sizeof(_Float16));
 }
 
 // Split-K variant for launches with few output rows (a single scan's leg: M = 360..2490 rows against K up to 2304).
@@ -282,7 +320,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_bf16x3_dyn_k
 // a one-chunk register prefetch, no LDS and no barrier in the loop; the NS partial tiles are summed through LDS in
 // a fixed order at the end (deterministic).  Needs Cin % 8 == 0 (a lane's 8 consecutive k are 8 consecutive channels).
 template <int NT, int NS>
-__global__ __launch_bounds__(64 * NS) void conv_splitk_bf16x3_kernel(ConvArgsB a) {
+__global__ __launch_bounds__(64 * NS) void conv_splitk_f16x3_kernel(ConvArgsB a, float one) {
   constexpr int N = NT * 16;
   __shared__ float red[NS][16][N];
   const int tid = threadIdx.x;
@@ -304,8 +342,10 @@ __global__ __launch_bounds__(64 * NS) void conv_splitk_bf16x3_kernel(ConvArgsB a
 #pragma unroll
   for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
+  const float inv = 1.0f / (s_in * a.sw);
   f32x4 av[2][2];
-  bf16x8 bv[2][NT][2];
+  f16x8 bv[2][NT][2];
   auto load = [&](int kc, int buf) {
     const int k = kc * KC + 8 * g;
     av[buf][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -317,27 +357,27 @@ __global__ __launch_bounds__(64 * NS) void conv_splitk_bf16x3_kernel(ConvArgsB a
       av[buf][0] = *reinterpret_cast<const f32x4*>(p);
       av[buf][1] = *reinterpret_cast<const f32x4*>(p + 4);
     }
-    const __bf16* wsrc = a.wp + (long long)kc * NT * 1024 + lane * 8;
+    const _Float16* wsrc = a.wp + (long long)kc * NT * 1024 + lane * 8;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      bv[buf][j][0] = *reinterpret_cast<const bf16x8*>(wsrc + j * 1024);
-      bv[buf][j][1] = *reinterpret_cast<const bf16x8*>(wsrc + j * 1024 + 512);
+      bv[buf][j][0] = *reinterpret_cast<const f16x8*>(wsrc + j * 1024);
+      bv[buf][j][1] = *reinterpret_cast<const f16x8*>(wsrc + j * 1024 + 512);
     }
   };
   auto compute = [&](int buf) {
     unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split_pair_rne(av[buf][0][0], av[buf][0][1], h0, l0);
-    split_pair_rne(av[buf][0][2], av[buf][0][3], h1, l1);
-    split_pair_rne(av[buf][1][0], av[buf][1][1], h2, l2);
-    split_pair_rne(av[buf][1][2], av[buf][1][3], h3, l3);
-    const bf16x8 ah = __builtin_bit_cast(bf16x8, (u32x4){h0, h1, h2, h3});
-    const bf16x8 al = __builtin_bit_cast(bf16x8, (u32x4){l0, l1, l2, l3});
+    split_pair_f16(av[buf][0][0], av[buf][0][1], s_in, one, h0, l0);
+    split_pair_f16(av[buf][0][2], av[buf][0][3], s_in, one, h1, l1);
+    split_pair_f16(av[buf][1][0], av[buf][1][1], s_in, one, h2, l2);
+    split_pair_f16(av[buf][1][2], av[buf][1][3], s_in, one, h3, l3);
+    const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});
+    const f16x8 al = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv[buf][j][0], acc[j], 0, 0, 0);
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bv[buf][j][0], acc[j], 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bv[buf][j][0], acc[j], 0, 0, 0);
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bv[buf][j][0], acc[j], 0, 0, 0);
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bv[buf][j][1], acc[j], 0, 0, 0);
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bv[buf][j][1], acc[j], 0, 0, 0);
   };
 
   // chunks wave, wave + NS, ... ; two per iteration so that the register buffers are addressed statically
@@ -359,21 +399,26 @@ __global__ __launch_bounds__(64 * NS) void conv_splitk_bf16x3_kernel(ConvArgsB a
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][4 * g + r][16 * j + lrow] = acc[j][r];
   __syncthreads();
+  float vmax = 0.f;
   for (int e = tid; e < 16 * N; e += 64 * NS) {
     const int row = e / N;
     const int n = e - row * N;
     float v = red[0][row][n];
 #pragma unroll
     for (int w = 1; w < NS; ++w) v += red[w][row][n];
-    v += a.bias[n];
+    v = fmaf(v, inv, a.bias[n]);
     if (a.relu) v = fmaxf(v, 0.0f);
-    if (m0 + row < a.M) a.out[(m0 + row) * a.Cout + n] = v;
+    if (m0 + row < a.M) {
+      a.out[(m0 + row) * a.Cout + n] = v;
+      vmax = fmaxf(vmax, fabsf(v));
+    }
   }
+  if (a.out_max) fold_absmax(vmax, a.out_max);
 }
 
 template <int NT, int NS>
 int launch_conv_splitk(const ConvArgsB& a, hipStream_t stream) {
-  hipLaunchKernelGGL((conv_splitk_bf16x3_kernel<NT, NS>), dim3((unsigned)((a.M + 15) / 16)), dim3(64 * NS), 0, stream, a);
+  hipLaunchKernelGGL((conv_splitk_f16x3_kernel<NT, NS>), dim3((unsigned)((a.M + 15) / 16)), dim3(64 * NS), 0, stream, a, 1.0f);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -384,20 +429,20 @@ int launch_conv_b(const ConvArgsB& a, bool vec4, hipStream_t stream) {
   constexpr int BN = 16 * WN * WAVES_N;
   dim3 grid((unsigned)((a.M + BM - 1) / BM), (unsigned)(a.Cout / BN));
   dim3 block(64 * WAVES_M * WAVES_N);
-  constexpr size_t lds = 4 * (size_t)BM * A_STRIDE * sizeof(__bf16) + 2 * (size_t)BN * 128;
+  constexpr size_t lds = 4 * (size_t)BM * A_STRIDE * sizeof(_Float16) + 2 * (size_t)BN * 128;
   if constexpr (lds > 64 * 1024) {
-    int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), lds);
-    if (!rc) rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>), lds);
+    int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_f16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), lds);
+    if (!rc) rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_mfma_f16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>), lds);
     if (rc) return rc;
     if (vec4)
-      hipLaunchKernelGGL((conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((conv_mfma_f16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, lds, stream, a, 1.0f);
     else
-      hipLaunchKernelGGL((conv_mfma_bf16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, lds, stream, a);
+      hipLaunchKernelGGL((conv_mfma_f16x3_dyn_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, lds, stream, a, 1.0f);
   } else {
     if (vec4)
-      hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((conv_mfma_f16x3_kernel<WM, WN, WAVES_M, WAVES_N, true>), grid, block, 0, stream, a, 1.0f);
     else
-      hipLaunchKernelGGL((conv_mfma_bf16x3_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, 0, stream, a);
+      hipLaunchKernelGGL((conv_mfma_f16x3_kernel<WM, WN, WAVES_M, WAVES_N, false>), grid, block, 0, stream, a, 1.0f);
   }
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
@@ -405,28 +450,63 @@ int launch_conv_b(const ConvArgsB& a, bool vec4, hipStream_t stream) {
 
 }  // namespace
 
-int ovn_conv_prepare_bf16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream) {
+int ovn_conv_prepare_f16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream) {
   OVN_REQUIRE(L->cout % 16 == 0, OVN_ERR_ARG, "layer %s: cout=%d must be a multiple of 16", L->name.c_str(), L->cout);
   const int K = L->kh * L->kw * L->cin;
-  L->nkc_bf = (K + KC - 1) / KC;
-  const size_t elems = (size_t)L->nkc_bf * (L->cout / 16) * 1024;  // hi + lo
-  OVN_HIP_CHECK(hipMalloc(&L->wp_bf, elems * sizeof(__bf16)));
-  hipLaunchKernelGGL(conv_prep_bf16_kernel, dim3(256), dim3(256), 0, stream, kernel_dev,
-                     reinterpret_cast<__bf16*>(L->wp_bf), K, L->nkc_bf, L->cout);
+  const int nkc = (K + KC - 1) / KC;
+  float* dmax = nullptr;
+  OVN_HIP_CHECK(hipMalloc((void**)&dmax, sizeof(float)));
+  hipLaunchKernelGGL(conv_absmax_kernel, dim3(1), dim3(1024), 0, stream, kernel_dev, (long long)K * L->cout, dmax);
+  float hmax = 0.f;
+  hipError_t e = hipMemcpyAsync(&hmax, dmax, sizeof(float), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(dmax);
+  OVN_HIP_CHECK(e);
+  L->sw_h = ovn_pow2_scale_for(hmax);
+  const size_t elems = (size_t)nkc * (L->cout / 16) * 1024;  // hi + lo
+  OVN_HIP_CHECK(hipMalloc(&L->wp_h, elems * sizeof(_Float16)));
+  hipLaunchKernelGGL(conv_prep_f16_kernel, dim3(256), dim3(256), 0, stream, kernel_dev, reinterpret_cast<_Float16*>(L->wp_h), K,
+                     nkc, L->cout, L->sw_h);
   OVN_HIP_CHECK(hipGetLastError());
   OVN_HIP_CHECK(hipStreamSynchronize(stream));
   return OVN_OK;
 }
 
-int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh_out,
-                            int* ow_out, hipStream_t stream, bool few_rows) {
-  OVN_REQUIRE(L.wp_bf != nullptr && L.bias != nullptr, OVN_ERR_STATE, "layer %s has no bf16x3 weights", L.name.c_str());
+// |x| maximum of n floats folded into *out_max (float bits; zero it first)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out_max) {
+  float m = 0.f;
+  const long long n4 = n >> 2;
+  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = x4[i];
+    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
+  fold_absmax(m, out_max);
+}
+
+int ovn_absmax_forward(const float* x, long long n, unsigned* out_max, hipStream_t stream) {
+  OVN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, OVN_ERR_ARG, "ovn_absmax_forward: input must be 16-byte aligned");
+  const long long want = (n / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, x, n, out_max);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh_out,
+                           int* ow_out, const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows) {
+  OVN_REQUIRE(L.wp_h != nullptr && L.bias != nullptr, OVN_ERR_STATE, "layer %s has no f16x3 weights", L.name.c_str());
+  OVN_REQUIRE(in_max != nullptr, OVN_ERR_ARG, "layer %s: f16x3 arithmetic needs the input maximum", L.name.c_str());
   OVN_REQUIRE(h >= L.kh && w >= L.kw, OVN_ERR_ARG, "layer %s: input %dx%d smaller than kernel", L.name.c_str(), h, w);
   ConvArgsB a;
   a.in = in;
-  a.wp = reinterpret_cast<const __bf16*>(L.wp_bf);
+  a.wp = reinterpret_cast<const _Float16*>(L.wp_h);
   a.bias = L.bias;
   a.out = out;
+  a.in_max = in_max;
+  a.out_max = out_max;
+  a.sw = L.sw_h;
   a.H = h;
   a.W = w;
   a.Cin = L.cin;
@@ -436,7 +516,7 @@ int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int 
   a.SH = L.sh;
   a.SW = L.sw;
   a.K = L.kh * L.kw * L.cin;
-  a.nkc = L.nkc_bf;
+  a.nkc = (a.K + KC - 1) / KC;
   a.KWC = L.kw * L.cin;
   a.rowstride = w * L.cin;
   a.M = (long long)nb * a.OH * a.OW;
@@ -447,7 +527,7 @@ int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int 
   {  // many scans of s_conv3 / s_conv3a: input strip resident in LDS (conv_strip.hip)
     static const int strip = getenv("OVN_CONV_STRIP") ? atoi(getenv("OVN_CONV_STRIP")) : 1;
     if (strip && !few_rows) {
-      const int took = ovn_conv_strip_try(L, in, nb, h, w, out, stream);
+      const int took = ovn_conv_strip_try(L, in, nb, h, w, out, in_max, out_max, stream);
       if (took < 0) return -took;
       if (took > 0) return OVN_OK;
     }

@@ -225,8 +225,8 @@ int ovn_conv_prepare(OvnConvLayer* L, const float* kernel_dev, const float* bias
 void ovn_conv_release(OvnConvLayer* L) {
   if (L->wp) (void)hipFree(L->wp);
   if (L->bias) (void)hipFree(L->bias);
-  if (L->wp_bf) (void)hipFree(L->wp_bf);
-  L->wp_bf = nullptr;
+  if (L->wp_h) (void)hipFree(L->wp_h);
+  L->wp_h = nullptr;
   L->wp = nullptr;
   L->bias = nullptr;
 }

@@ -1,8 +1,9 @@
-// KH x KW / stride (SH,1) convolutions + bias + ReLU with the input strip resident in LDS, for gfx950 (bf16x3 arithmetic).
+// KH x KW / stride (SH,1) convolutions + bias + ReLU with the input strip resident in LDS, for gfx950 (f16x3 arithmetic: scaled
+// fp16 hi/lo split, see conv_f16x3.hip / delta_head_f16x3.hip).
 //
 // Reference: the leg layers s_conv3 .. s_conv10 (generateNet.py:173-214): 3x15 and 3x12 with stride (2,1) to 64 channels,
 // 2x9 stride (2,1) and the 1xKW layers to 128 channels -- 70 % of the batched leg's time in the generic implicit-GEMM
-// kernel (conv_bf16x3.hip), which gathers and splits every input element once per tap that touches it (up to 22x) and
+// kernel (conv_f16x3.hip), which gathers and splits every input element once per tap that touches it (up to 22x) and
 // pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a workgroup owns TW output pixels
 // of one output row: the KH input rows it needs ((TW + KW - 1) pixels x CIN channels each) are loaded and split ONCE into
 // an LDS-resident hi/lo strip and every tap is a compile-time address offset into it (the K walk is fully unrolled).
@@ -18,16 +19,20 @@
 
 #include "ovn_internal.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
 struct StripArgs {
   const float* in;
-  const __bf16* wp;
+  const _Float16* wp;
   const float* bias;
   float* out;
+  const unsigned* in_max;   // float bits of max |input| of the call (device)
+  unsigned* out_max;        // NULL or where max |output| is folded
+  float sw, one;            // weight scale; 1.0f (keeps v_fma_mix selectable, see conv_f16x3.hip)
   int H, W, OH, OW, XT;   // input rows / cols, output rows / cols, x tiles per output row
 };
 
@@ -41,7 +46,7 @@ struct StripCfg {
   static constexpr int MTH = (MT + MSPLIT - 1) / MSPLIT;   // m-tiles per wave
   static constexpr int CC = CIN / 32;                  // 32-channel chunks per tap
   static constexpr int NK = KH * KW * CC;              // K steps
-  static constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(__bf16) + 1024;   // + slack for padded-row reads
+  static constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 1024;   // + slack for padded-row reads
 };
 
 template <int CIN, int KH, int SH, int KW, int TW, int NT>
@@ -50,8 +55,11 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   constexpr int COUT = 16 * NT;
   constexpr int PLANE = C::PLANE, PIX = C::PIX, MTH = C::MTH, CC = C::CC, NK = C::NK;
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
-  __bf16* sh = reinterpret_cast<__bf16*>(strip_smem);
-  __bf16* sl = sh + C::NPL * PLANE;
+  _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
+  _Float16* sl = sh + C::NPL * PLANE;
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
+  const float inv = 1.0f / (s_in * a.sw);
+  const float one = a.one;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,15 +109,19 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
           const int r = i - row * (PIX * Q);
           const int pix = r / Q;
           const int c = 4 * (r - pix * Q);
-          bf16x4 h, l;
+          f16x4 h, l;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            h[e] = (__bf16)v[u][e];
-            l[e] = (__bf16)(v[u][e] - (float)h[e]);
+          for (int e = 0; e < 4; e += 2) {
+            const float x0 = v[u][e] * s_in, x1 = v[u][e + 1] * s_in;
+            const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+            h[e] = hp[0];
+            h[e + 1] = hp[1];
+            l[e] = (_Float16)__builtin_fmaf(x0, one, -(float)hp[0]);
+            l[e + 1] = (_Float16)__builtin_fmaf(x1, one, -(float)hp[1]);
           }
           const int o = (c >> 3) * PLANE + (row * PIX + pix) * 8 + (c & 7);
-          *reinterpret_cast<bf16x4*>(sh + o) = h;
-          *reinterpret_cast<bf16x4*>(sl + o) = l;
+          *reinterpret_cast<f16x4*>(sh + o) = h;
+          *reinterpret_cast<f16x4*>(sl + o) = l;
         }
       }
     }
@@ -119,22 +131,22 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   // = 256 B further, a tap (ky, kx) and a channel chunk are compile-time offsets because the K loop is fully unrolled
   // -> no address arithmetic in the loop.  (Rows of the last, partly padded m-tile read a few pixels past the tile; those
   // accumulators are never stored, and the allocation has slack for the last plane.)
-  const __bf16* ah_base = sh + g * PLANE + (16 * wm * MTH + lrow) * 8;
-  const __bf16* al_base = sl + g * PLANE + (16 * wm * MTH + lrow) * 8;
+  const _Float16* ah_base = sh + g * PLANE + (16 * wm * MTH + lrow) * 8;
+  const _Float16* al_base = sl + g * PLANE + (16 * wm * MTH + lrow) * 8;
   f32x4 acc[MTH];
 #pragma unroll
   for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // weights [kc][nt(NT)][hi,lo][lane][8]: wave-uniform base (scalar) + one per-lane offset
-  const __bf16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512);
+  const _Float16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512);
   const int wlane = lane * 8;
-  bf16x8 bq[3][2];
-  bf16x8 fh[2][MTH], fl[2][MTH];
+  f16x8 bq[3][2];
+  f16x8 fh[2][MTH], fl[2][MTH];
 #define STRIP_LOAD_B(SLOT, KS)                                                     \
   {                                                                                \
-    const __bf16* q = wbase + (size_t)(KS) * (NT * 2 * 512);                       \
-    bq[SLOT][0] = *reinterpret_cast<const bf16x8*>(q + wlane);                     \
-    bq[SLOT][1] = *reinterpret_cast<const bf16x8*>(q + 512 + wlane);               \
+    const _Float16* q = wbase + (size_t)(KS) * (NT * 2 * 512);                       \
+    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(q + wlane);                     \
+    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(q + 512 + wlane);               \
   }
 #define STRIP_READ_A(BUF, KS)                                                      \
   {                                                                                \
@@ -142,17 +154,17 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
     constexpr int ky_ = tap_ / KW;                                                 \
     constexpr int toff_ = (ky_ * PIX + (tap_ - ky_ * KW)) * 8 + 4 * PLANE * ((KS) - tap_ * CC); \
     _Pragma("unroll") for (int i = 0; i < MTH; ++i) {                              \
-      fh[BUF][i] = *reinterpret_cast<const bf16x8*>(ah_base + toff_ + i * 128);    \
-      fl[BUF][i] = *reinterpret_cast<const bf16x8*>(al_base + toff_ + i * 128);    \
+      fh[BUF][i] = *reinterpret_cast<const f16x8*>(ah_base + toff_ + i * 128);    \
+      fl[BUF][i] = *reinterpret_cast<const f16x8*>(al_base + toff_ + i * 128);    \
     }                                                                              \
   }
 #define STRIP_MFMA(BUF, SLOT)                                                                                  \
   _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
   _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
   _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[BUF][i], bq[SLOT][1], acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[BUF][i], bq[SLOT][1], acc[i], 0, 0, 0);
   STRIP_LOAD_B(0, 0)
   STRIP_LOAD_B(1, 1)
   __syncthreads();  // strip complete
@@ -176,24 +188,39 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   const int n = 16 * wn + lrow;
   const float bv = a.bias[n];
   float* orow = a.out + (((long long)b * a.OH + oy) * a.OW + x0) * COUT;
+  float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < MTH; ++i) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int p = 16 * (wm * MTH + i) + 4 * g + r;
-      if (p < tw) orow[(long long)p * COUT + n] = fmaxf(acc[i][r] + bv, 0.0f);
+      if (p < tw) {
+        const float v = fmaxf(fmaf(acc[i][r], inv, bv), 0.0f);
+        orow[(long long)p * COUT + n] = v;
+        vmax = fmaxf(vmax, v);
+      }
     }
+  }
+  if (a.out_max) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0) atomicMax(a.out_max, __float_as_uint(vmax));
   }
 }
 
 template <int CIN, int KH, int SH, int KW, int TW, int NT>
-int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, hipStream_t stream, bool* took) {
+int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max, unsigned* out_max,
+                 hipStream_t stream, bool* took) {
   typedef StripCfg<CIN, KH, KW, TW, NT> C;
   StripArgs a;
   a.in = in;
-  a.wp = reinterpret_cast<const __bf16*>(L.wp_bf);
+  a.wp = reinterpret_cast<const _Float16*>(L.wp_h);
   a.bias = L.bias;
   a.out = out;
+  a.in_max = in_max;
+  a.out_max = out_max;
+  a.sw = L.sw_h;
+  a.one = 1.0f;
   a.H = h;
   a.W = w;
   a.OH = (h - KH) / SH + 1;
@@ -214,8 +241,9 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, f
 static int pad_rows(int ow, int tw) { return (ow + tw - 1) / tw * tw - ow; }   // padded output pixels per row with tiles of tw
 
 // Returns 1 when the layer / call was taken (result in out), 0 when the caller should use the generic kernel, < 0 on error.
-int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, hipStream_t stream) {
-  if (!(L.sw == 1 && L.relu && L.wp_bf != nullptr) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return 0;
+int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max,
+                       unsigned* out_max, hipStream_t stream) {
+  if (!(L.sw == 1 && L.relu && L.wp_h != nullptr) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return 0;
   if (h < L.kh || w < L.kw) return 0;
   bool took = false;
   int rc = OVN_OK;
@@ -223,28 +251,28 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, in
   if (L.kh > 1 && L.sh != 2) return 0;
   if (L.kh == 1 && L.sh != 1) return 0;
   switch (key) {
-    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 208, 4>(L, in, nb, h, w, out, stream, &took); break;   // s_conv3
-    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 135, 4>(L, in, nb, h, w, out, stream, &took); break;   // s_conv3a
+    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 208, 4>(L, in, nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3
+    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 135, 4>(L, in, nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3a
     // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
     case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
-      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, h, w, out, stream, &took)
-                                                                 : launch_strip<64, 2, 2, 9, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<64, 2, 2, 9, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 9) * 1000 + 128) * 1000 + 128:   // s_conv5-7
-      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, h, w, out, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 9, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 9, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 7) * 1000 + 128) * 1000 + 128:   // s_conv8
-      rc = (pad_rows(w - 7 + 1, 80) <= pad_rows(w - 7 + 1, 96)) ? launch_strip<128, 1, 1, 7, 80, 8>(L, in, nb, h, w, out, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 7, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      rc = (pad_rows(w - 7 + 1, 80) <= pad_rows(w - 7 + 1, 96)) ? launch_strip<128, 1, 1, 7, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 7, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 5) * 1000 + 128) * 1000 + 128:   // s_conv9
-      rc = (pad_rows(w - 5 + 1, 80) <= pad_rows(w - 5 + 1, 96)) ? launch_strip<128, 1, 1, 5, 80, 8>(L, in, nb, h, w, out, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 5, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      rc = (pad_rows(w - 5 + 1, 80) <= pad_rows(w - 5 + 1, 96)) ? launch_strip<128, 1, 1, 5, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 5, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 3) * 1000 + 128) * 1000 + 128:   // s_conv10
-      rc = (pad_rows(w - 3 + 1, 80) <= pad_rows(w - 3 + 1, 96)) ? launch_strip<128, 1, 1, 3, 80, 8>(L, in, nb, h, w, out, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 3, 96, 8>(L, in, nb, h, w, out, stream, &took);
+      rc = (pad_rows(w - 3 + 1, 80) <= pad_rows(w - 3 + 1, 96)) ? launch_strip<128, 1, 1, 3, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 3, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     default: return 0;
   }

@@ -1,0 +1,747 @@
+// Delta head: DeltaLayer + c_conv1 + c_conv2 fused, on the fp16 matrix cores with a scaled 3-term split
+// (v_mfma_f32_16x16x32_f16, fp32 accumulate) for gfx950.  Reference: generateNet.py:15-61 (DeltaLayer), :96-106.
+//
+// Arithmetic ("f16x3"): every fp32 operand x is scaled by a power of two s (exact) and written as hi + lo, both fp16:
+// 11 + 11 significand bits, i.e. x*s is carried to 2^-21 relative, or to 2^-25 ABSOLUTE in scaled units once lo falls below
+// the fp16 normal range (scales put the largest operand at 2^13..2^14, so that floor is < 2^-38 of it).  a*w is evaluated
+// as a_hi*w_hi + a_lo*w_hi + a_hi*w_lo: three MFMAs at the fp16 rate (16x the fp32 matrix rate); the dropped a_lo*w_lo term
+// is 2^-22 relative.  Products and sums are fp32 inside the MFMA, the scales are divided out of the fp32 accumulators.
+//
+// The DeltaLayer in MIN FORM.  c_conv1 needs sum_k |l - r| w.  Forming and splitting |l - r| costs 5-8 VALU instructions per
+// element pair next to the 12 MFMAs they feed, and the matrix pipe hides only part of that (tools/experiments/ubench3.hip,
+// ubench5.hip: 12 MFMAs alone 94 ns, with the bf16 split 130 ns, with an fp16 split via v_cvt_pkrtz / v_fma_mix 122 ns --
+// the conversions issue at a fraction of the plain VALU rate).  Instead:
+//     |l - r| = l + r - 2 min(l, r)
+//   * the l and r terms are LINEAR: sum_k l w collapses to a 360 x 128 x 64 product per left volume (T, with the kernel
+//     summed over its 15 taps), sum_k r w to a 24 x 1920 x 64 product per right volume (A2) -- 0.6 % of the work, done once
+//     per pair (delta_prepare_kernel) / once per right volume (delta_a2_kernel) on the fp32 matrix cores;
+//   * min(l, r) COMMUTES with the split: for x >= 0 the word P(x) = fp16 hi(x) << 16 | fp16 lo(x) (hi truncated, so lo >= 0)
+//     orders like x, hence P(min(l, r)) = min_u32(P(l), P(r)).  Both volumes are packed once per pair (L by the prepare
+//     kernel, R rows when they are staged in LDS) and the inner loop is ONE v_min_u32 per element plus two v_perm_b32 per
+//     element pair that separate the hi and lo halves: 4 full-rate VALU per pair instead of 8 (100 ns per 12 MFMAs in
+//     ubench5.hip, the 12 MFMAs alone take 94).
+//   The accumulators start at -(T + A2)/2 (scaled), so the 1920-deep contraction ends at -(c_conv1 output)/2 directly.
+//   Inputs need not be non-negative: a pair is shifted by c = -min(0, smallest value) first (|l - r| does not change).
+//   Numerics: l + r - 2 min(l, r) is evaluated without the rounding of the fp32 subtraction the reference performs, but the
+//   three sums are ~1.5x larger than the result, so the fp32 accumulation error is that of an fp32 evaluation times ~2-3
+//   (1e-6 of the largest c_conv1 output; tests/test_parity_sweep.py compares every pair of the benchmark sweep with fp64).
+//
+// Scales: weights statically (max |W| -> 2^14), features per PAIR (max over both volumes -> 2^14, so a pair's result does
+// not depend on the other pairs of the call), the c_conv1 output by the bound |b1|max + max|l - r| max_o sum|W1[.,o]|.
+//
+// Work decomposition of the main kernel: one workgroup (8 waves) = one pair; wave w owns rows 48w..48w+47 (3 MFMA row tiles)
+// of the 360 x 64 c_conv1 output of TWO column groups jb, jb+1 at a time: the K walk of c_conv1 is shared by the two groups,
+// so every W1 fragment read from LDS, every staged W1 chunk, every barrier and every L slice load serves 24 MFMAs per row
+// tile.  K = (c, dj) is walked channel-slice-major: an MFMA step covers 32 channels (lane group g = lane>>4 takes channels
+// 32g + 8s .. 32g + 8s + 7 for slice s = 0..3) of one R row dj, and the 15 rows dj of a slice are consecutive steps -- a lane
+// needs only 8 words of L per row tile at a time.  W1 (hi and lo, pre-permuted to this order) streams through a
+// double-buffered 2 x 24 KB LDS window shared by the 8 waves; o1 goes to LDS as hi/lo fp16 in GEMM2's [24][960] A layout;
+// GEMM2 (c_conv2) reads its weights straight from L2, software-pipelined.  Earlier schedules: tools/experiments/.
+#include <math.h>
+#include <stdlib.h>
+
+#include "ovn_internal.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int FW = OVN_FEAT_W;        // 360
+constexpr int FC = OVN_FEAT_C;        // 128
+constexpr int S = OVN_S;              // 15
+constexpr int G = OVN_G;              // 24
+constexpr int O1 = OVN_C1_OUT;        // 64
+constexpr int O2 = OVN_C2_OUT;        // 128
+constexpr int K1 = S * FC;            // 1920
+constexpr int K2 = S * O1;            // 960
+constexpr int O1_STRIDE = K2 + 8;     // fp16 elements per o1 row in LDS: 1936 B = 121 16-B slots (odd)
+constexpr int STEPS_PER_CHUNK = 3;    // MFMA steps per W1 window chunk; 5 chunks = one 15-step channel slice
+constexpr int NCHUNK = 4 * S / STEPS_PER_CHUNK;   // 20 chunks per column group
+constexpr int STEP_BYTES = 8192;      // [nt(4)][hi/lo][lane(64)][8 fp16]
+constexpr int CHUNK_BYTES = STEPS_PER_CHUNK * STEP_BYTES;
+constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + 2 * (size_t)S * FC * 4 + 2 * CHUNK_BYTES;
+constexpr int NWAVE = 8;
+constexpr int TL_ELEMS = NWAVE * 3 * 4 * 64 * 4;   // floats of T per pair in accumulator order [wave][t][nt][lane][r]
+constexpr int A2_ELEMS = G * O1;                   // floats of A2 per right volume [jb][o]
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split_f16(float x, _Float16& hi, _Float16& lo) {
+  hi = (_Float16)x;
+  lo = (_Float16)(x - (float)hi);
+}
+
+// P(x0), P(x1) for two scaled non-negative values: word = fp16_rtz(x) << 16 | fp16_rne(x - hi).
+__device__ __forceinline__ void pack_pair(float x0, float x1, unsigned& w0, unsigned& w1) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  f16x2 lo;
+  lo[0] = (_Float16)(x0 - (float)h[0]);
+  lo[1] = (_Float16)(x1 - (float)h[1]);
+  const unsigned hp = __builtin_bit_cast(unsigned, h), lp = __builtin_bit_cast(unsigned, lo);
+  w0 = __builtin_amdgcn_perm(hp, lp, 0x05040100u);   // h0 << 16 | l0
+  w1 = __builtin_amdgcn_perm(hp, lp, 0x07060302u);   // h1 << 16 | l1
+}
+
+__device__ __forceinline__ u32x4 pack4(const f32x4& v, float sa, float csa) {
+  u32x4 w;
+  unsigned a, b;
+  pack_pair(fmaf(v[0], sa, csa), fmaf(v[1], sa, csa), a, b);
+  w[0] = a;
+  w[1] = b;
+  pack_pair(fmaf(v[2], sa, csa), fmaf(v[3], sa, csa), a, b);
+  w[2] = a;
+  w[3] = b;
+  return w;
+}
+
+// A fragments (hi, lo) of min(l, r) for one 16-row tile and one MFMA step: 8 packed words per lane each side.
+__device__ __forceinline__ void make_a(const u32x4& l0, const u32x4& l1, const u32x4& r0, const u32x4& r1, f16x8& ah, f16x8& al) {
+  u32x4 h, q;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    const unsigned m0 = min(l0[2 * p], r0[2 * p]), m1 = min(l0[2 * p + 1], r0[2 * p + 1]);
+    h[p] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+    q[p] = __builtin_amdgcn_perm(m1, m0, 0x05040100u);
+    const unsigned n0 = min(l1[2 * p], r1[2 * p]), n1 = min(l1[2 * p + 1], r1[2 * p + 1]);
+    h[2 + p] = __builtin_amdgcn_perm(n1, n0, 0x07060302u);
+    q[2 + p] = __builtin_amdgcn_perm(n1, n0, 0x05040100u);
+  }
+  ah = __builtin_bit_cast(f16x8, h);
+  al = __builtin_bit_cast(f16x8, q);
+}
+
+// out[0] = max |w|, out[1] = max over columns n of sum_k |w[k][n]| for a row-major [K][N] matrix; one workgroup.
+__global__ __launch_bounds__(256) void delta_wstats_kernel(const float* __restrict__ w, int K, int N, float* __restrict__ out) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  float amax = 0.f, cmax = 0.f;
+  for (int n = tid; n < N; n += 256) {
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = fabsf(w[(size_t)k * N + n]);
+      s += v;
+      amax = fmaxf(amax, v);
+    }
+    cmax = fmaxf(cmax, s);
+  }
+  red[tid] = amax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  const float a = red[0];
+  __syncthreads();
+  red[tid] = cmax;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    out[0] = a;
+    out[1] = red[0];
+  }
+}
+
+// w1sum[c][o] = sum_dj W1[dj][c][o] (fp64 accumulation, rounded once) and w1col[o] = sum_{dj,c} W1[dj][c][o].
+__global__ __launch_bounds__(256) void delta_w1sum_kernel(const float* __restrict__ w1, float* __restrict__ w1sum, float* __restrict__ w1col) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < FC * O1) {
+    double s = 0.0;
+    for (int dj = 0; dj < S; ++dj) s += (double)w1[(size_t)dj * FC * O1 + idx];
+    w1sum[idx] = (float)s;
+  }
+  if (idx < O1) {
+    double s = 0.0;
+    for (int k = 0; k < K1; ++k) s += (double)w1[(size_t)k * O1 + idx];
+    w1col[idx] = (float)s;
+  }
+}
+
+// W1p[u = s*15 + dj][nt(4)][hl(2)][lane(64)][e(8)]: sw * W1[dj][c = 32*(lane>>4) + 8*s + e][o = 16*nt + (lane&15)]
+__global__ void delta_prep_w1_f16_kernel(const float* __restrict__ w1, _Float16* __restrict__ w1p, float sw) {
+  const int total = S * 4 * 4 * 64 * 8;  // (hi, lo) pairs
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 3;
+    const int u = idx >> 11;  // 0..59
+    const int s = u / S;
+    const int dj = u - s * S;
+    const int c = 32 * (lane >> 4) + 8 * s + e;
+    const int o = 16 * nt + (lane & 15);
+    _Float16 hi, lo;
+    split_f16(sw * w1[(dj * FC + c) * O1 + o], hi, lo);
+    const size_t base = (((size_t)u * 4 + nt) * 2) * 512 + lane * 8 + e;
+    w1p[base] = hi;
+    w1p[base + 512] = lo;
+  }
+}
+
+// W2p[ks(30)][nt(8)][hl(2)][lane(64)][e(8)]: sw * W2[k(k')][p = 16*nt + (lane&15)], k' = 32*ks + 8*(lane>>4) + e.
+// GEMM2 walks its K axis in the order k' = di*64 + 4*(o & 15) + (o >> 4) instead of k = di*64 + o: the four c_conv1
+// n-tiles a lane holds after GEMM1 (o = lrow, 16+lrow, 32+lrow, 48+lrow) are then adjacent in the o1 image, so the
+// epilogue stores 8 bytes per (row, hi/lo) instead of four 2-byte pieces.  Any K order works as long as A and B agree.
+__global__ void delta_prep_w2_f16_kernel(const float* __restrict__ w2, _Float16* __restrict__ w2p, float sw) {
+  const int total = (K2 / 32) * 8 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 7;
+    const int ks = idx >> 12;
+    const int kp = 32 * ks + 8 * (lane >> 4) + e;
+    const int m = kp & 63;
+    const int k = (kp & ~63) + 16 * (m & 3) + (m >> 2);
+    const int p = 16 * nt + (lane & 15);
+    _Float16 hi, lo;
+    split_f16(sw * w2[k * O2 + p], hi, lo);
+    const size_t base = (((size_t)ks * 8 + nt) * 2) * 512 + lane * 8 + e;
+    w2p[base] = hi;
+    w2p[base + 512] = lo;
+  }
+}
+
+// A2raw[v][jb][o] = sum_{dj,c} R_v[15 jb + dj][c] W1[dj][c][o] for right volume v (v = ridx[b] if ridx else 0), on the fp32
+// matrix cores (v_mfma_f32_16x16x4_f32: an fp32 FMA chain).  One workgroup per volume, wave = (m-tile of 16 jb, n-tile of 16 o):
+// rows 15jb .. 15jb+14 of R are contiguous, so the A operand of output row jb is simply R_v[1920 jb + k].
+__global__ __launch_bounds__(512) void delta_a2_kernel(const float* __restrict__ feats_r, const int32_t* __restrict__ ridx,
+                                                       const float* __restrict__ w1raw, float* __restrict__ a2raw) {
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const int mt = wave >> 2, nt = wave & 3;
+  const float* R = feats_r + (long long)(ridx ? ridx[b] : 0) * OVN_FEAT_ELEMS;
+  const int jb = 16 * mt + lrow;
+  const float* arow = R + (size_t)(jb < G ? jb : G - 1) * K1 + g;
+  const float* bcol = w1raw + (size_t)g * O1 + 16 * nt + lrow;
+  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // independent chains
+#pragma unroll 2
+  for (int ks = 0; ks < K1 / 4; ks += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * (ks + u)], bcol[(size_t)4 * (ks + u) * O1], acc[u], 0, 0, 0);
+  }
+  const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 16 * mt + 4 * g + r;
+    if (row < G) a2raw[(size_t)b * A2_ELEMS + row * O1 + 16 * nt + lrow] = s[r];
+  }
+}
+
+// Per pair: value range of both volumes -> shift c and the power-of-two scales; L packed into P words; T = b1 + (L + c) Ws on
+// the fp32 matrix cores, stored pre-scaled by -(sa sw1)/2 in the main kernel's accumulator order; A2 likewise (from A2raw).
+// scales[2 pair] = {sa, 1/(sa sw1), s1, 1/(s1 sw2)}, scales[2 pair + 1] = {c sa, ...}.  o2max[pair] = 0.
+__global__ __launch_bounds__(512) void delta_prepare_kernel(const float* __restrict__ feats_l, const int32_t* __restrict__ lidx,
+                                                            const float* __restrict__ feats_r, const int32_t* __restrict__ ridx,
+                                                            const float* __restrict__ w1sum, const float* __restrict__ w1col,
+                                                            const float* __restrict__ b1, const float* __restrict__ a2raw,
+                                                            float sw1, float sw2, float w1_colsum, float b1_absmax,
+                                                            f32x4* __restrict__ scales, unsigned* __restrict__ o2max,
+                                                            unsigned* __restrict__ pl, float* __restrict__ tl, float* __restrict__ a2s) {
+  __shared__ float red[2][NWAVE];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const float* Lf = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
+  const float* Rf = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4* L4 = reinterpret_cast<const f32x4*>(Lf);
+  const f32x4* R4 = reinterpret_cast<const f32x4*>(Rf);
+  float mx = -3.0e38f, mn = 3.0e38f;
+  for (int i = tid; i < OVN_FEAT_ELEMS / 4; i += 512) {
+    const f32x4 a = L4[i], b = R4[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+    mn = fminf(mn, fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(b[0], b[1]), fminf(b[2], b[3]))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+  }
+  if (lane == 0) {
+    red[0][wave] = mx;
+    red[1][wave] = mn;
+  }
+  __syncthreads();
+  mx = red[0][0];
+  mn = red[1][0];
+#pragma unroll
+  for (int w = 1; w < NWAVE; ++w) {
+    mx = fmaxf(mx, red[0][w]);
+    mn = fminf(mn, red[1][w]);
+  }
+  const float c = (mn < 0.0f) ? -mn : 0.0f;       // shift that makes both volumes non-negative
+  const float span = mx + c;                       // largest shifted value = bound of |l - r|
+  const float sa = ovn_pow2_scale_for(span);
+  const float s1 = ovn_pow2_scale_for(b1_absmax + span * w1_colsum);
+  const float csa = c * sa;
+  const float kneg = -0.5f * sa * sw1;
+  if (tid == 0) {
+    scales[2 * pair] = (f32x4){sa, 1.0f / (sa * sw1), s1, 1.0f / (s1 * sw2)};
+    scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
+    o2max[pair] = 0u;   // running max of the pair's c_conv2 output (float bits; values are >= 0), filled by the main kernel
+  }
+  // L -> packed words
+  u32x4* P4 = reinterpret_cast<u32x4*>(pl + (size_t)pair * OVN_FEAT_ELEMS);
+  for (int i = tid; i < OVN_FEAT_ELEMS / 4; i += 512) P4[i] = pack4(L4[i], sa, csa);
+  // A2 of this pair: (A2raw + c wcol) kneg
+  {
+    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_ELEMS;
+    float* dst = a2s + (size_t)pair * A2_ELEMS;
+    for (int i = tid; i < A2_ELEMS; i += 512) dst[i] = (src[i] + c * w1col[i & (O1 - 1)]) * kneg;
+  }
+  // T: wave w, row tiles 3w .. 3w+2, all four n-tiles; K = 128 in 32 steps of 4
+  float* tdst = tl + (size_t)pair * TL_ELEMS + (size_t)wave * (3 * 4 * 64 * 4) + lane * 4;
+#pragma unroll 1
+  for (int t = 0; t < 3; ++t) {
+    const int i = 48 * wave + 16 * t + lrow;
+    const float* arow = Lf + (size_t)(i < FW ? i : FW - 1) * FC + g;
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+    for (int ks = 0; ks < FC / 4; ++ks) {
+      const float a = arow[4 * ks];
+      const float* brow = w1sum + (size_t)(4 * ks + g) * O1 + lrow;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[16 * nt], acc[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float add = b1[16 * nt + lrow] + c * w1col[16 * nt + lrow];
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (48 * wave + 16 * t + 4 * g + r < FW) ? (acc[nt][r] + add) * kneg : 0.0f;
+      *reinterpret_cast<f32x4*>(tdst + (size_t)(t * 4 + nt) * 256) = v;
+    }
+  }
+}
+
+// ABL: timing-only ablations for tools/delta_ablate.py (wrong results; compiled only with -DOVN_ABLATE, product = 0):
+//   1 no epilogue / GEMM2, 2 no L slice reloads, 4 no W1 staging, 8 no chunk barrier, 16 no min/perm VALU, 32 no GEMM1 MFMAs,
+//   64 no pass prologue (R staging, T/A2 loads)
+template <int T, int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned* __restrict__ pl,
+                                                                  const float* __restrict__ tl, const float* __restrict__ a2s,
+                                                                  const float* __restrict__ feats_r,
+                                                                  const int32_t* __restrict__ ridx,
+                                                                  const _Float16* __restrict__ w1p,
+                                                                  const _Float16* __restrict__ w2p,
+                                                                  const float* __restrict__ b2,
+                                                                  const f32x4* __restrict__ scales, float* __restrict__ o2,
+                                                                  unsigned* __restrict__ o2max, int rot, int nsplit) {
+  static_assert(T == 3 && NW == NWAVE, "T is stored for 8 waves x 3 row tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* o1h = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* o1l = o1h + G * O1_STRIDE;
+  unsigned* rs = reinterpret_cast<unsigned*>(o1l + G * O1_STRIDE);       // packed R rows of the two column groups
+  unsigned char* wst = reinterpret_cast<unsigned char*>(rs + 2 * S * FC);  // 2 x 24 KB window
+
+  // nsplit > 1 (small sweeps): the 12 column-group passes of a pair are spread over nsplit workgroups, so that a handful of
+  // pairs still fills the chip (a pair's latency drops from 1.4 ms to 1.4 / nsplit ms; no work is duplicated)
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const unsigned* L = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4 sc = scales[2 * pair];
+  const float sa = sc[0], inv_a1 = sc[1], s1 = sc[2], inv_2 = sc[3];
+  const float csa = scales[2 * pair + 1][0];
+
+  // this lane's slice of L for channel slice s: rows 48*wave + 16*t + lrow, channels 32g + 8s .. +7
+  constexpr int NT_ = 64 * NW;                       // threads
+  constexpr int PFN = CHUNK_BYTES / (NT_ * 16);      // 16-byte window pieces per thread per chunk
+  static_assert(CHUNK_BYTES % (NT_ * 16) == 0 && T * NW * 16 >= FW, "bad tiling");
+  int lrow_off[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = 16 * T * wave + 16 * t + lrow;
+    lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
+  }
+  u32x4 la[T][2];
+#define OVN_LOAD_L(DST, SL)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
+    if ((ABL & 2) && (SL) != s0) {                                                                       \
+    } else if (lrow_off[t] >= 0) {                                                                              \
+      DST[t][0] = *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL));                           \
+      DST[t][1] = *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                       \
+    } else {                                                                                             \
+      DST[t][0] = (u32x4){0u, 0u, 0u, 0u};                                                               \
+      DST[t][1] = (u32x4){0u, 0u, 0u, 0u};                                                               \
+    }                                                                                                    \
+  }
+  // Workgroups walk the channel slices (and with them the W1 stream) in rotated order: the 32 CUs of an XCD then
+  // touch every W1 line several times per column-group period instead of in one burst, which keeps the 1 MB of
+  // weights resident in the 4 MB L2 under the private L / o2 streams (LRU thrash otherwise: 18.7 GB/launch of misses).
+  const int s0 = rot ? ((pair >> 3) & 3) : 0;
+  const int s1i = (s0 + 1) & 3, s2i = (s0 + 2) & 3, s3i = (s0 + 3) & 3;
+  OVN_LOAD_L(la, s0)
+
+  // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 20 chunks, so the window just wraps)
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  f32x4 pf[PFN];
+#pragma unroll
+  for (int q = 0; q < PFN; ++q) {
+    pf[q] = *reinterpret_cast<const f32x4*>(w1bytes + (size_t)(5 * s0) * CHUNK_BYTES + (q * NT_ + tid) * 16);
+    *reinterpret_cast<f32x4*>(wst + (q * NT_ + tid) * 16) = pf[q];
+  }
+  int cur = 0;
+  int chunk = 5 * s0;  // running chunk index 0..19 (cyclic), 5 chunks per slice
+
+  // 12 MFMAs of one row tile; term-major so consecutive MFMAs never chain on one accumulator
+#define OVN_TILE_MFMA(J, T, AH, AL)                                                                       \
+  if (ABL & 32) {                                                                                          \
+    acc[J][T][0] += __builtin_bit_cast(f32x4, AH);                                                         \
+    acc[J][T][1] += __builtin_bit_cast(f32x4, AL);                                                         \
+  } else {                                                                                                 \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, bh[nt], acc[J][T][nt], 0, 0, 0);         \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, bh[nt], acc[J][T][nt], 0, 0, 0);         \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, bl[nt], acc[J][T][nt], 0, 0, 0);         \
+  }
+  // One channel slice SL (15 MFMA steps = 5 window chunks) with the L slice held in LX.
+#define OVN_SLICE(LX, SL)                                                                                         \
+  {                                                                                                               \
+    for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
+      const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
+      const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
+      if (!(ABL & 4)) {                                                                                           \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
+          pf[q] = *reinterpret_cast<const f32x4*>(src + (q * NT_ + tid) * 16);                                    \
+      }                                                                                                           \
+      _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
+        const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
+        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
+        const unsigned* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                  \
+        const u32x4 ra0 = *reinterpret_cast<const u32x4*>(rrow);                                                  \
+        const u32x4 ra1 = *reinterpret_cast<const u32x4*>(rrow + 4);                                              \
+        const u32x4 rb0 = *reinterpret_cast<const u32x4*>(rrow + S * FC);                                         \
+        const u32x4 rb1 = *reinterpret_cast<const u32x4*>(rrow + S * FC + 4);                                     \
+        f16x8 bh[4], bl[4];                                                                                       \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
+          bh[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                       \
+          bl[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                       \
+        }                                                                                                         \
+        _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                           \
+          f16x8 ah, al;                                                                                           \
+          if (ABL & 16) {                                                                                         \
+            ah = __builtin_bit_cast(f16x8, LX[t][0] ^ ra0);                                                       \
+            al = __builtin_bit_cast(f16x8, LX[t][1] ^ ra1);                                                       \
+          } else make_a(LX[t][0], LX[t][1], ra0, ra1, ah, al);                                                    \
+          OVN_TILE_MFMA(0, t, ah, al)                                                                             \
+          if (ABL & 16) {                                                                                         \
+            ah = __builtin_bit_cast(f16x8, LX[t][0] ^ rb0);                                                       \
+            al = __builtin_bit_cast(f16x8, LX[t][1] ^ rb1);                                                       \
+          } else make_a(LX[t][0], LX[t][1], rb0, rb1, ah, al);                                                    \
+          OVN_TILE_MFMA(1, t, ah, al)                                                                             \
+        }                                                                                                         \
+      }                                                                                                           \
+      if (!(ABL & 4)) {                                                                                           \
+        unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                      \
+        _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                           \
+            *reinterpret_cast<f32x4*>(dstw + (q * NT_ + tid) * 16) = pf[q];                                       \
+      }                                                                                                           \
+      if (!(ABL & 8)) __syncthreads();                                                                            \
+      cur ^= 1;                                                                                                   \
+      chunk = nxt;                                                                                                \
+    }                                                                                                             \
+  }
+
+  const f32x4* tsrc = reinterpret_cast<const f32x4*>(tl + (size_t)pair * TL_ELEMS + (size_t)wave * (T * 4 * 64 * 4) + lane * 4);
+  const float* a2p = a2s + (size_t)pair * A2_ELEMS + lrow;
+
+  for (int jb2 = part * (G / 2) / nsplit; jb2 < (part + 1) * (G / 2) / nsplit; ++jb2) {
+    __syncthreads();  // previous pass's GEMM2 is done with o1h/o1l and rs; W window write above is visible
+    if (!(ABL & 64))
+    for (int i4 = tid; i4 < 2 * S * FC / 4; i4 += NT_)
+      *reinterpret_cast<u32x4*>(rs + 4 * i4) = pack4(*reinterpret_cast<const f32x4*>(R + jb2 * 2 * S * FC + 4 * i4), sa, csa);
+
+    // accumulators start at -(T[i][o] + A2[jb][o]) (sa sw1) / 2: the contraction then ends at -(c_conv1 output)(sa sw1)/2
+    f32x4 acc[2][T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (ABL & 64) {
+          acc[0][t][nt] = acc[1][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
+        const f32x4 tv = tsrc[(t * 4 + nt) * 64];
+        acc[0][t][nt] = tv + a2p[(2 * jb2) * O1 + 16 * nt];
+        acc[1][t][nt] = tv + a2p[(2 * jb2 + 1) * O1 + 16 * nt];
+      }
+    __syncthreads();
+
+    // single L register set (the second accumulator set took the ping-pong's registers): each slice load is exposed
+    OVN_SLICE(la, s0)
+    OVN_LOAD_L(la, s1i)
+    OVN_SLICE(la, s1i)
+    OVN_LOAD_L(la, s2i)
+    OVN_SLICE(la, s2i)
+    OVN_LOAD_L(la, s3i)
+    OVN_SLICE(la, s3i)
+    OVN_LOAD_L(la, s0)
+
+    if (ABL & 1) {   // keep the accumulators alive
+      f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) sacc += acc[j][t][nt];
+      if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 123.456f) o2[tid] = sacc[0];
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+    const int jb = 2 * jb2 + j;
+    if (j == 1) __syncthreads();  // GEMM2 of the first group is done with the o1 image
+    // o1 = -2 acc / (sa sw1), scaled by s1 -> LDS as hi/lo fp16 in GEMM2's A layout (K order k' = di*64 + 4*lrow + nt, see the
+    // W2 prep kernel).  C/D: lane holds column lrow of every n-tile, rows 4g..4g+3: one 8-byte store for the 4 hi parts, one
+    // for the lo parts.
+    {
+      const float k1 = -2.0f * inv_a1 * s1;   // powers of two: exact
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * T * wave + 16 * t + 4 * g + r;
+          if (i < FW) {
+            const int ib = i / S;
+            const int di = i - ib * S;
+            f16x4 h4, l4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              _Float16 h, l;
+              split_f16(acc[j][t][nt][r] * k1, h, l);
+              h4[nt] = h;
+              l4[nt] = l;
+            }
+            *reinterpret_cast<f16x4*>(o1h + ib * O1_STRIDE + di * O1 + 4 * lrow) = h4;
+            *reinterpret_cast<f16x4*>(o1l + ib * O1_STRIDE + di * O1 + 4 * lrow) = l4;
+          }
+        }
+      }
+    }
+    __syncthreads();
+
+    // GEMM2 (24 x 960) x (960 x 128): wave w owns output columns 16w..16w+15 for BOTH 16-row m-tiles, so every
+    // W2 fragment is fetched from L2 by exactly one wave of the workgroup (491 KB per column group, not 2x that).
+    {
+      const int ib0 = lrow;                                   // m-tile 0: rows 0..15
+      const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;  // m-tile 1: rows 16..23 (+ 8 padding rows)
+      const _Float16* a0h = o1h + ib0 * O1_STRIDE + 8 * g;
+      const _Float16* a0l = o1l + ib0 * O1_STRIDE + 8 * g;
+      const _Float16* a1h = o1h + ib1 * O1_STRIDE + 8 * g;
+      const _Float16* a1l = o1l + ib1 * O1_STRIDE + 8 * g;
+      const _Float16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;
+      // one accumulator per (m-tile, split term): six independent MFMA chains per k-step instead of two -- with only two
+      // accumulators every MFMA waited on the one issued two before it (this wave's whole GEMM2 is 2 x 1 tiles)
+      f32x4 acc2t[2][3];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc2t[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int ks0 = rot ? 6 * ((pair >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
+      // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
+      // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
+      constexpr int GB = 3, NB = K2 / 32 / GB;
+      static_assert(NB % 2 == 0, "the batch loop is unrolled by two");
+      f16x8 wq0[GB][2], wq1[GB][2];
+      auto ksof = [&](int kk) { const int ks = kk + ks0; return ks >= K2 / 32 ? ks - K2 / 32 : ks; };
+#define OVN_W2_LOAD(DST, B)                                                        \
+  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
+    const _Float16* wk = wcol + (size_t)ksof((B) * GB + u) * (8 * 2 * 512);        \
+    DST[u][0] = *reinterpret_cast<const f16x8*>(wk);                               \
+    DST[u][1] = *reinterpret_cast<const f16x8*>(wk + 512);                         \
+  }
+// o1 fragments are read from LDS one k-step ahead of the MFMAs that consume them
+#define OVN_W2_READ_A(SLOT, B, U)                                                  \
+  {                                                                                \
+    const int ks_ = ksof((B) * GB + (U));                                          \
+    af[SLOT][0] = *reinterpret_cast<const f16x8*>(a0h + 32 * ks_);                 \
+    af[SLOT][1] = *reinterpret_cast<const f16x8*>(a0l + 32 * ks_);                 \
+    af[SLOT][2] = *reinterpret_cast<const f16x8*>(a1h + 32 * ks_);                 \
+    af[SLOT][3] = *reinterpret_cast<const f16x8*>(a1l + 32 * ks_);                 \
+  }
+#define OVN_W2_COMPUTE(SRC, B)                                                     \
+  {                                                                                \
+    f16x8 af[2][4];                                                                \
+    OVN_W2_READ_A(0, B, 0)                                                         \
+    _Pragma("unroll") for (int u = 0; u < GB; ++u) {                               \
+      if (u + 1 < GB) OVN_W2_READ_A((u + 1) & 1, B, u + 1)                         \
+      __builtin_amdgcn_sched_barrier(0);                                           \
+      acc2t[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][0], SRC[u][0], acc2t[0][0], 0, 0, 0); \
+      acc2t[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][2], SRC[u][0], acc2t[1][0], 0, 0, 0); \
+      acc2t[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][1], SRC[u][0], acc2t[0][1], 0, 0, 0); \
+      acc2t[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][3], SRC[u][0], acc2t[1][1], 0, 0, 0); \
+      acc2t[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][0], SRC[u][1], acc2t[0][2], 0, 0, 0); \
+      acc2t[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][2], SRC[u][1], acc2t[1][2], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                           \
+    }                                                                              \
+  }
+      OVN_W2_LOAD(wq0, 0)
+#pragma unroll 1
+      for (int b = 0; b < NB; b += 2) {
+        OVN_W2_LOAD(wq1, b + 1)
+        OVN_W2_COMPUTE(wq0, b)
+        if (b + 2 < NB) {
+          OVN_W2_LOAD(wq0, b + 2)
+        }
+        OVN_W2_COMPUTE(wq1, b + 1)
+      }
+#undef OVN_W2_LOAD
+#undef OVN_W2_COMPUTE
+#undef OVN_W2_READ_A
+      f32x4 acc2[2];
+      acc2[0] = (acc2t[0][0] + acc2t[0][1]) + acc2t[0][2];
+      acc2[1] = (acc2t[1][0] + acc2t[1][1]) + acc2t[1][2];
+      const int p = 16 * wave + lrow;
+      const float bv = b2[p];
+      float vmax = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ib2 = 16 * mt + 4 * g + r;
+          if (ib2 < G) {
+            const float v = fmaxf(fmaf(acc2[mt][r], inv_2, bv), 0.0f);
+            o2[(((long long)pair * G + ib2) * G + jb) * O2 + p] = v;
+            vmax = fmaxf(vmax, v);
+          }
+        }
+      }
+      // the pair's max c_conv2 output, for the scale of the fp16 split in c3_dense (non-negative floats order like their bits)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+      if (lane == 0) atomicMax(o2max + pair, __float_as_uint(vmax));
+    }
+    }
+  }
+}
+
+#undef OVN_LOAD_L
+#undef OVN_SLICE
+#undef OVN_TILE_MFMA
+}  // namespace
+
+size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
+         al((size_t)n * TL_ELEMS * sizeof(float)) + al((size_t)n * A2_ELEMS * sizeof(float)) +
+         al((size_t)(per_pair_right ? n : 1) * A2_ELEMS * sizeof(float));
+}
+
+int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_kernel<3, 8>), LDS_BYTES);
+  if (rc) return rc;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  char* p = static_cast<char*>(scratch);
+  f32x4* scales = reinterpret_cast<f32x4*>(p);
+  p += al((size_t)n * 8 * sizeof(float));
+  unsigned* o2max = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * sizeof(unsigned));
+  unsigned* pl = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned));
+  float* tl = reinterpret_cast<float*>(p);
+  p += al((size_t)n * TL_ELEMS * sizeof(float));
+  float* a2s = reinterpret_cast<float*>(p);
+  p += al((size_t)n * A2_ELEMS * sizeof(float));
+  float* a2raw = reinterpret_cast<float*>(p);
+  *o2max_out = o2max;
+  // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
+  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair, W1 window and R rows set up once)
+  int nsplit = 1;
+  {
+    double best = 1e30;
+    for (const int d : {1, 2, 3, 4, 6, 12}) {
+      const double cost = (double)(((long long)n * d + 255) / 256) / d;
+      if (cost < best) best = cost;
+    }
+    for (const int d : {1, 2, 3, 4, 6, 12}) {
+      const double cost = (double)(((long long)n * d + 255) / 256) / d;
+      if (cost <= 1.05 * best) {
+        nsplit = d;
+        break;
+      }
+    }
+  }
+  {
+    OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
+    hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
+    hipLaunchKernelGGL(delta_prepare_kernel, dim3(n), dim3(512), 0, stream, feats_l, lidx, feats_r, ridx, ctx->w1sum, ctx->w1col,
+                       ctx->b1, a2raw, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.w1_colsum, ctx->hs.b1_absmax, scales, o2max, pl, tl, a2s);
+  }
+  OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+#define OVN_DELTA_LAUNCH(ABLV)                                                                                                  \
+  hipLaunchKernelGGL((delta_c12_f16x3_kernel<3, 8, ABLV>), dim3(n * nsplit), dim3(512), LDS_BYTES, stream, pl, tl, a2s, feats_r, ridx, \
+                     reinterpret_cast<const _Float16*>(ctx->w1p_h), reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->c2.bias,  \
+                     scales, o2, o2max, 1, nsplit)
+#ifdef OVN_ABLATE
+  {
+    const int abl = getenv("OVN_DELTA_ABL") ? atoi(getenv("OVN_DELTA_ABL")) : 0;
+#define OVN_ABL_CASE(V)                                                                                          \
+  case V:                                                                                                        \
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_kernel<3, 8, V>), LDS_BYTES);       \
+    if (rc) return rc;                                                                                           \
+    OVN_DELTA_LAUNCH(V);                                                                                         \
+    break;
+    switch (abl) {
+      OVN_ABL_CASE(0) OVN_ABL_CASE(1) OVN_ABL_CASE(2) OVN_ABL_CASE(4) OVN_ABL_CASE(12) OVN_ABL_CASE(16) OVN_ABL_CASE(32)
+      OVN_ABL_CASE(64) OVN_ABL_CASE(67) OVN_ABL_CASE(79) OVN_ABL_CASE(95) OVN_ABL_CASE(111) OVN_ABL_CASE(48)
+      default: ovn_set_error("OVN_DELTA_ABL=%d not compiled", abl); return OVN_ERR_ARG;
+    }
+  }
+#else
+  OVN_DELTA_LAUNCH(0);
+#endif
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+// Weight statistics (host copies: this call synchronises `stream`, like every weight registration), the tap-summed c_conv1
+// kernel of the linear terms, and the scaled fp16 hi/lo fragments of c_conv1 / c_conv2.
+int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const float* c1_bias_dev, const float* c2_kernel_dev,
+                            hipStream_t stream) {
+  OvnHeadScales* hs = &ctx->hs;
+  float* stats = nullptr;
+  OVN_HIP_CHECK(hipMalloc((void**)&stats, 6 * sizeof(float)));
+  hipLaunchKernelGGL(delta_wstats_kernel, dim3(1), dim3(256), 0, stream, c1_kernel_dev, K1, O1, stats);
+  hipLaunchKernelGGL(delta_wstats_kernel, dim3(1), dim3(256), 0, stream, c2_kernel_dev, K2, O2, stats + 2);
+  hipLaunchKernelGGL(delta_wstats_kernel, dim3(1), dim3(256), 0, stream, c1_bias_dev, 1, O1, stats + 4);
+  float h[6];
+  hipError_t e = hipMemcpyAsync(h, stats, sizeof(h), hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  (void)hipFree(stats);
+  OVN_HIP_CHECK(e);
+  hs->sw1 = ovn_pow2_scale_for(h[0]);
+  hs->w1_colsum = h[1];
+  hs->sw2 = ovn_pow2_scale_for(h[2]);
+  hs->b1_absmax = h[4];
+  const size_t w1_elems = (size_t)S * FC * O1 * 2;   // hi + lo
+  const size_t w2_elems = (size_t)K2 * O2 * 2;
+  OVN_HIP_CHECK(hipMalloc(&ctx->w1p_h, w1_elems * sizeof(_Float16)));
+  OVN_HIP_CHECK(hipMalloc(&ctx->w2p_h, w2_elems * sizeof(_Float16)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1raw, (size_t)K1 * O1 * sizeof(float)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1sum, (size_t)FC * O1 * sizeof(float)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1col, (size_t)O1 * sizeof(float)));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->w1raw, c1_kernel_dev, (size_t)K1 * O1 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(delta_w1sum_kernel, dim3((FC * O1 + 255) / 256), dim3(256), 0, stream, c1_kernel_dev, ctx->w1sum, ctx->w1col);
+  hipLaunchKernelGGL(delta_prep_w1_f16_kernel, dim3(240), dim3(256), 0, stream, c1_kernel_dev,
+                     reinterpret_cast<_Float16*>(ctx->w1p_h), hs->sw1);
+  hipLaunchKernelGGL(delta_prep_w2_f16_kernel, dim3(240), dim3(256), 0, stream, c2_kernel_dev,
+                     reinterpret_cast<_Float16*>(ctx->w2p_h), hs->sw2);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}

@@ -90,9 +90,13 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->b1) (void)hipFree(ctx->b1);
   if (ctx->wd) (void)hipFree(ctx->wd);
   if (ctx->bd) (void)hipFree(ctx->bd);
-  if (ctx->w1p_bf) (void)hipFree(ctx->w1p_bf);
-  if (ctx->w2p_bf) (void)hipFree(ctx->w2p_bf);
+  if (ctx->w1p_h) (void)hipFree(ctx->w1p_h);
+  if (ctx->w2p_h) (void)hipFree(ctx->w2p_h);
+  if (ctx->w1raw) (void)hipFree(ctx->w1raw);
+  if (ctx->w1sum) (void)hipFree(ctx->w1sum);
+  if (ctx->w1col) (void)hipFree(ctx->w1col);
   if (ctx->ws) (void)hipFree(ctx->ws);
+  if (ctx->actmax) (void)hipFree(ctx->actmax);
   delete ctx;
   return OVN_OK;
 }
@@ -117,7 +121,7 @@ int ovn_add_leg_layer(ovn_ctx* ctx, const char* name, const float* kernel_dev, c
   L.relu = 1;  // every leg layer is Conv2D(..., activation='relu'), generateNet.py:161-214
   int rc = ovn_conv_prepare(&L, kernel_dev, bias_dev, (hipStream_t)stream);
   if (rc) return rc;
-  rc = ovn_conv_prepare_bf16x3(&L, kernel_dev, (hipStream_t)stream);
+  rc = ovn_conv_prepare_f16x3(&L, kernel_dev, (hipStream_t)stream);
   if (rc) {
     ovn_conv_release(&L);
     return rc;
@@ -138,9 +142,13 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
     if (ctx->b1) (void)hipFree(ctx->b1);
     if (ctx->wd) (void)hipFree(ctx->wd);
     if (ctx->bd) (void)hipFree(ctx->bd);
-    if (ctx->w1p_bf) (void)hipFree(ctx->w1p_bf);
-    if (ctx->w2p_bf) (void)hipFree(ctx->w2p_bf);
-    ctx->w1p_bf = ctx->w2p_bf = nullptr;
+    if (ctx->w1p_h) (void)hipFree(ctx->w1p_h);
+    if (ctx->w2p_h) (void)hipFree(ctx->w2p_h);
+    if (ctx->w1raw) (void)hipFree(ctx->w1raw);
+    if (ctx->w1sum) (void)hipFree(ctx->w1sum);
+    if (ctx->w1col) (void)hipFree(ctx->w1col);
+    ctx->w1p_h = ctx->w2p_h = nullptr;
+    ctx->w1raw = ctx->w1sum = ctx->w1col = nullptr;
     ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
     ctx->head_set = false;
   }
@@ -160,7 +168,7 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
   ctx->c2.relu = 1;
   rc = ovn_conv_prepare(&ctx->c2, c2k, c2b, stream);
   if (rc) return rc;
-  rc = ovn_delta_prepare_bf16x3(c1k, c2k, &ctx->w1p_bf, &ctx->w2p_bf, stream);
+  rc = ovn_delta_prepare_f16x3(ctx, c1k, c1b, c2k, stream);
   if (rc) return rc;
   ctx->c3 = OvnConvLayer();
   ctx->c3.name = "c_conv3";
@@ -173,7 +181,7 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
   ctx->c3.relu = 1;
   rc = ovn_conv_prepare(&ctx->c3, c3k, c3b, stream);
   if (rc) return rc;
-  rc = ovn_conv_prepare_bf16x3(&ctx->c3, c3k, stream);
+  rc = ovn_conv_prepare_f16x3(&ctx->c3, c3k, stream);
   if (rc) return rc;
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->wd, (size_t)OVN_DENSE_IN * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->bd, sizeof(float)));
@@ -227,10 +235,18 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
   if (rc) return rc;
   float* buf[2] = {reinterpret_cast<float*>(ctx->ws), reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + buf_bytes)};
   const size_t in_elems = (size_t)ctx->in_h * ctx->in_w * ctx->in_c;
+  OVN_REQUIRE(ctx->leg.size() + 1 <= OVN_ACTMAX_SLOTS, OVN_ERR_STATE, "ovn_leg: too many leg layers");
+  if (ctx->leg_mode != 0 && !ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, OVN_ACTMAX_SLOTS * sizeof(unsigned)));
   for (int64_t s0 = 0; s0 < n; s0 += slice) {
     const int nb = (int)((n - s0 < slice) ? (n - s0) : slice);
     const float* cur = images_dev + (size_t)s0 * in_elems;
     int h = ctx->in_h, w = ctx->in_w;
+    if (ctx->leg_mode != 0) {   // f16x3: slot li = max |input of layer li| of this slice, folded by the producing kernel
+      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, OVN_ACTMAX_SLOTS * sizeof(unsigned), stream));
+      OvnProfScope ps(ctx, OVN_K_LEG, stream);
+      rc = ovn_absmax_forward(cur, (long long)nb * (long long)in_elems, ctx->actmax, stream);
+      if (rc) return rc;
+    }
     for (size_t li = 0; li < ctx->leg.size(); ++li) {
       const bool last = (li + 1 == ctx->leg.size());
       float* dst = last ? features_dev + (size_t)s0 * OVN_FEAT_ELEMS : buf[li & 1];
@@ -238,7 +254,8 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
-                                  : ovn_conv_forward_bf16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream, n <= 8);
+                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li,
+                                                           last ? nullptr : ctx->actmax + li + 1, stream, n <= 8);
       }
       if (rc) return rc;
       cur = dst;
@@ -290,15 +307,20 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   const int64_t chunk = 2048;                                   // pairs per pass: 1.6 GB of scratch
   const int64_t cmax = n < chunk ? n : chunk;
   const size_t o2_bytes = ((size_t)cmax * o2_elems * sizeof(float) + 255) & ~(size_t)255;
-  // second scratch region: o3 (n,22,22,256) in fp32 mode; in bf16x3 mode c_conv3 and the Dense layer are one kernel and only
+  // second scratch region: o3 (n,22,22,256) in fp32 mode; in f16x3 mode c_conv3 and the Dense layer are one kernel and only
   // 3 partial sums per pair leave it
   const bool fused = (ctx->head_mode != 0);
   const size_t o3_bytes = fused ? (((size_t)cmax * 3 * sizeof(float) + 255) & ~(size_t)255)
                                 : (((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255);
-  int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes, stream);
+  // f16x3 mode: per-pair scales, packed left volumes and linear terms of the min-form Delta kernel (289 KB per pair)
+  const size_t sc_bytes = fused ? ovn_delta_f16x3_scratch_bytes((int)cmax, ridx != nullptr) : 0;
+  int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes + sc_bytes, stream);
   if (rc) return rc;
   float* o2 = reinterpret_cast<float*>(ctx->ws);
   float* o3 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + o2_bytes);
+  void* dscratch = static_cast<char*>(ctx->ws) + o2_bytes + o3_bytes;
+  unsigned* o2max = nullptr;
+  ctx->dbg_o2max = nullptr;
   ctx->dbg_o2 = o2;
   ctx->dbg_o3 = fused ? nullptr : o3;
   ctx->dbg_partial = fused ? o3 : nullptr;
@@ -313,16 +335,18 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
       rc = ovn_corr_forward(fl, li, feats_r, ri, np, yaw + p0, corr ? corr + (size_t)p0 * OVN_FEAT_W : nullptr, stream);
       if (rc) return rc;
     }
-    {
+    if (fused) {   // times its prepare kernels and the main kernel separately
+      rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch, &o2max, o2, stream);
+      if (p0 == 0) ctx->dbg_o2max = o2max;
+    } else {
       OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-      rc = (ctx->head_mode == 0) ? ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream)
-                                 : ovn_delta_c12_bf16x3_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
+      rc = ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
     }
     if (rc) return rc;
     if (fused) {
       {
         OvnProfScope ps(ctx, OVN_K_C3, stream);
-        rc = ovn_c3_dense_forward(ctx, o2, np, o3, nullptr, stream);
+        rc = ovn_c3_dense_forward(ctx, o2, o2max, np, o3, nullptr, stream);
       }
       if (rc) return rc;
       OvnProfScope ps(ctx, OVN_K_DENSE, stream);
@@ -420,14 +444,14 @@ int ovn_gt_overlap_counts(ovn_ctx* ctx, const float* ref_ranges_dev, const float
 
 int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
-  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = f16x3 MFMA)", mode);
   ctx->head_mode = mode;
   return OVN_OK;
 }
 
 int ovn_set_leg_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_leg_precision: ctx is NULL");
-  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_leg_precision: mode %d (0 = fp32 MFMA, 1 = bf16x3 MFMA)", mode);
+  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_leg_precision: mode %d (0 = fp32 MFMA, 1 = f16x3 MFMA)", mode);
   ctx->leg_mode = mode;
   return OVN_OK;
 }
@@ -475,9 +499,13 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
   OVN_REQUIRE(in_dev && out_dev && nb >= 0, OVN_ERR_ARG, "ovn_debug_conv: bad buffers");
   OVN_HIP_CHECK(hipSetDevice(ctx->device));
   int oh = 0, ow = 0;
-  return (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream)
-                              : ovn_conv_forward_bf16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream,
-                                                        nb <= 8);
+  if (ctx->leg_mode == 0) return ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
+  if (!ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, OVN_ACTMAX_SLOTS * sizeof(unsigned)));
+  OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, OVN_ACTMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream));
+  int rc = ovn_absmax_forward(in_dev, (long long)nb * h * w * ctx->leg[layer].cin, ctx->actmax, (hipStream_t)stream);
+  if (rc) return rc;
+  return ovn_conv_forward_f16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, ctx->actmax, ctx->actmax + 1,
+                                (hipStream_t)stream, nb <= 8);
 }
 
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream) {
@@ -490,8 +518,8 @@ int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3
   if (o3_dev && ctx->dbg_o3)
     OVN_HIP_CHECK(hipMemcpyAsync(o3_dev, ctx->dbg_o3, (size_t)n * OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));
-  else if (o3_dev)  // bf16x3 mode: o3 never left the fused kernel -- run it again on the o2 still in scratch, with o3 output
-    return ovn_c3_dense_forward(ctx, ctx->dbg_o2, (int)n, ctx->dbg_partial, o3_dev, (hipStream_t)stream);
+  else if (o3_dev)  // f16x3 mode: o3 never left the fused kernel -- run it again on the o2 still in scratch, with o3 output
+    return ovn_c3_dense_forward(ctx, ctx->dbg_o2, ctx->dbg_o2max, (int)n, ctx->dbg_partial, o3_dev, (hipStream_t)stream);
   return OVN_OK;
 }
 

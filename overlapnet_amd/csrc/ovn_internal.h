@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 
 #include <string>
@@ -42,8 +43,28 @@ constexpr int OVN_C2_OUT = 128;   // c_conv2 filters
 constexpr int OVN_C3_OUT = 256;   // c_conv3 filters
 constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
 constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
+constexpr int OVN_ACTMAX_SLOTS = 32;                           // per-layer activation maxima of a leg call (f16x3 scales)
 constexpr int OVN_SPEC_W = 368;                                 // floats per spectrum row: Re[0..180] | pad | Im at 184.. | pad
 constexpr int OVN_SPEC_ELEMS = OVN_FEAT_C * OVN_SPEC_W;        // 47104 floats = 188,416 B per scan
+
+// ---- scaled fp16 hi/lo arithmetic ("f16x3") ----------------------------------------------------------
+// Power-of-two scale that brings a tensor whose largest magnitude is m into [2^13, 2^14): 2^(14 - e) with 2^(e-1) <= m < 2^e.
+// fp16 holds 2^14 with 2x headroom below 65504; m == 0, Inf or NaN -> 1 (nothing to protect).
+__host__ __device__ inline float ovn_pow2_scale_for(float m) {
+  if (!(m > 0.0f) || !(m < 3.0e38f)) return 1.0f;
+  int e = 0;
+  (void)frexpf(m, &e);
+  int k = 14 - e;
+  k = k > 100 ? 100 : (k < -100 ? -100 : k);
+  return ldexpf(1.0f, k);
+}
+
+// static scales / norms of the Delta-head weights (delta_head_f16x3.hip)
+struct OvnHeadScales {
+  float sw1 = 1.f, sw2 = 1.f;     // power-of-two scales of the c_conv1 / c_conv2 kernels
+  float w1_colsum = 0.f;          // max over output channels o of sum |W1[., ., o]|: bound of c_conv1's output per unit input
+  float b1_absmax = 0.f;
+};
 
 // ---- a convolution layer in MFMA fragment order ----------------------------------------------------
 // Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and one process may hold
@@ -60,8 +81,8 @@ struct OvnConvLayer {
   int nkc = 0;    // ceil(K/16)
   float* wp = nullptr;    // [nkc][cout/16][64][4] fragment-ordered copy (device)
   float* bias = nullptr;  // [cout] (device)
-  void* wp_bf = nullptr;  // optional hi/lo bf16 fragments [ceil(K/32)][cout/16][2][64][8] (conv_bf16x3.hip)
-  int nkc_bf = 0;
+  void* wp_h = nullptr;   // optional hi/lo fp16 fragments of sw_h * W, [ceil(K/32)][cout/16][2][64][8] (conv_f16x3.hip)
+  float sw_h = 1.f;       // power-of-two weight scale of wp_h
 };
 
 struct ovn_ctx {
@@ -76,10 +97,15 @@ struct ovn_ctx {
   float* b1 = nullptr;
   OvnConvLayer c2;       // c_conv2 as a [960][128] GEMM operand in fragment order
   OvnConvLayer c3;       // c_conv3 as a regular conv layer
-  void* w1p_bf = nullptr;  // c_conv1 hi/lo bf16 fragments (delta_head_bf16x3.hip)
-  void* w2p_bf = nullptr;  // c_conv2 hi/lo bf16 fragments
-  int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = 3-term bf16 split on the bf16 MFMA (conv_bf16x3.hip)
-  int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = 3-term bf16 split on the bf16 MFMA
+  void* w1p_h = nullptr;   // c_conv1 / c_conv2 scaled hi/lo fp16 fragments (delta_head_f16x3.hip)
+  void* w2p_h = nullptr;
+  float* w1raw = nullptr;  // c_conv1 kernel as registered, [1920][64]: B operand of the right-volume linear term
+  float* w1sum = nullptr;  // c_conv1 kernel summed over its 15 taps, [128][64]: B operand of the left-volume linear term
+  float* w1col = nullptr;  // [64] column sums of the c_conv1 kernel (shift term)
+  OvnHeadScales hs;
+  int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
+  unsigned* actmax = nullptr;   // [32] float bits of max |activation| per leg layer input of the running call (f16x3 scales)
+  int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = scaled 3-term fp16 split on the fp16 MFMA (default)
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
   // spectral correlation head: constant twiddle layers (corr_spectral.hip)
@@ -96,14 +122,15 @@ struct ovn_ctx {
   };
   std::vector<ProfRec> prof_recs;
   const float* dbg_o2 = nullptr;
-  const float* dbg_o3 = nullptr;   // fp32 head mode only; in bf16x3 mode o3 is recomputed on request (dbg_partial = scratch)
+  const float* dbg_o3 = nullptr;   // fp32 head mode only; in f16x3 mode o3 is recomputed on request (dbg_partial = scratch)
   float* dbg_partial = nullptr;
+  const unsigned* dbg_o2max = nullptr;
   int64_t dbg_n = 0;
 };
 
 // kernel classes reported by ovn_profile_end
 enum { OVN_K_LEG = 0, OVN_K_CORR = 1, OVN_K_DELTA = 2, OVN_K_C3 = 3, OVN_K_DENSE = 4, OVN_K_PROJ = 5, OVN_K_SPECTRUM = 6,
-       OVN_K_CORR_SPECTRAL = 7, OVN_K_COUNT = 8 };
+       OVN_K_CORR_SPECTRAL = 7, OVN_K_DELTA_PREP = 8, OVN_K_COUNT = 9 };
 
 struct OvnProfScope {
   ovn_ctx* ctx;
@@ -130,12 +157,16 @@ void ovn_conv_release(OvnConvLayer* L);
 int ovn_conv_forward(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh,
                      int* ow, hipStream_t stream);
 
-// conv_bf16x3.hip
-int ovn_conv_prepare_bf16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream);
+// conv_f16x3.hip
+// scaled fp16 hi/lo fragments of the layer (wp_h, sw_h); synchronises `stream` (the weight maximum is read back)
+int ovn_conv_prepare_f16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream);
+// in_max: float bits of max |in| over the call (device word, left there by the producer of `in` or by ovn_absmax_forward);
+// out_max: NULL, or a zeroed device word into which max |out| is folded for the next layer.
 // few_rows: the whole call (not just this slice) is a handful of scans -> the split-K kernels may be used; decided by
-// the caller so that every scan of one call takes the same code path (bit-identical results per batch position)
-int ovn_conv_forward_bf16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh,
-                            int* ow, hipStream_t stream, bool few_rows = false);
+// the caller so that every scan of one call takes the same code path
+int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh, int* ow,
+                           const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows = false);
+int ovn_absmax_forward(const float* x, long long n, unsigned* out_max, hipStream_t stream);
 
 // delta_head.hip
 int ovn_delta_prepare_w1(const float* c1_kernel_dev, float** w1p_out, hipStream_t stream);
@@ -144,11 +175,14 @@ int ovn_delta_c12_forward(const ovn_ctx* ctx, const float* feats_l, const int32_
 int ovn_dense_sigmoid_forward(const ovn_ctx* ctx, const float* o3, int n, float* overlap, float* logit,
                               hipStream_t stream);
 
-// delta_head_bf16x3.hip
-int ovn_delta_prepare_bf16x3(const float* c1_kernel_dev, const float* c2_kernel_dev, void** w1p_out, void** w2p_out,
-                             hipStream_t stream);
-int ovn_delta_c12_bf16x3_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                 const int32_t* ridx, int n, float* o2, hipStream_t stream);
+// delta_head_f16x3.hip.  `scratch` (ovn_delta_f16x3_scratch_bytes(n, ridx != NULL) bytes, caller-owned) holds the per-pair
+// scales, the packed left volumes and the linear terms; *o2max_out points at the per-pair maxima of the c_conv2 output inside it
+// (input of ovn_c3_dense_forward).
+int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const float* c1_bias_dev, const float* c2_kernel_dev,
+                            hipStream_t stream);
+size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right);
+int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream);
 
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
@@ -157,11 +191,14 @@ int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* fea
 // corr_spectral.hip
 int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
-// conv_strip.hip: LDS-resident strip kernels for the 3 x KW / stride (2,1) leg layers with 64 outputs (bf16x3 mode)
-int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, hipStream_t stream);
+// conv_strip.hip: LDS-resident strip kernels for the 3 x KW / stride (2,1) leg layers with 64 outputs (f16x3 mode)
+int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max,
+                       unsigned* out_max, hipStream_t stream);
 
-// c3_dense.hip: c_conv3 + Flatten + Dense fused (bf16x3 mode), input patch resident in LDS
-int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, int n, float* partial, float* o3, hipStream_t stream);
+// c3_dense.hip: c_conv3 + Flatten + Dense fused (f16x3 mode), input patch resident in LDS
+// o2max: the per-pair maxima of o2 left by the f16x3 Delta kernel (scale of the fp16 split)
+int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
+                         hipStream_t stream);
 int ovn_dense_finish_forward(const ovn_ctx* ctx, const float* partial, int n, float* overlap, float* logit, hipStream_t stream);
 
 // overlap_gt.hip

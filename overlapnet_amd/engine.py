@@ -43,8 +43,8 @@ class OvnEngine:
         self.feat_w = 0
         self._leg_ready = False
         self._head_ready = False
-        self.head_precision = "bf16x3"
-        self.leg_precision = "bf16x3"
+        self.head_precision = "f16x3"
+        self.leg_precision = "f16x3"
 
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:
@@ -332,31 +332,33 @@ class OvnEngine:
         return o2, o3
 
     def set_head_precision(self, mode: str) -> None:
-        """'f32' = fp32 matrix cores, 'bf16x3' = 3-term bf16 split on the bf16 matrix cores (default)."""
-        table = {"f32": 0, "bf16x3": 1}
+        """Arithmetic of the Delta-head contractions (fp32 storage and accumulation in both modes):
+        'f16x3' (default) = scaled 3-term fp16 split on the fp16 matrix cores (22 significand bits per operand: the error of an
+        fp32 evaluation), 'f32' = fp32 matrix cores (bit-for-bit an fp32 FMA chain, 1/16 of the rate)."""
+        table = {"f32": 0, "f16x3": 1}
         if mode not in table:
             raise ValueError("head precision must be one of %s" % sorted(table))
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
         self.head_precision = mode
 
     def set_leg_precision(self, mode: str) -> None:
-        """'bf16x3' (default) = 3-term bf16 split on the bf16 matrix cores, 'f32' = fp32 matrix cores, for the leg convolutions."""
-        table = {"f32": 0, "bf16x3": 1}
+        """Arithmetic of the leg convolutions: 'f16x3' (default, as above) or 'f32' (fp32 matrix cores)."""
+        table = {"f32": 0, "f16x3": 1}
         if mode not in table:
             raise ValueError("leg precision must be one of %s" % sorted(table))
         _lib.check(self.lib.ovn_set_leg_precision(self._h, table[mode]), "ovn_set_leg_precision")
         self.leg_precision = mode
 
     PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection", "spectrum",
-                     "corr_spectral")
+                     "corr_spectral", "delta_prep")
 
     def profile_begin(self) -> None:
         _lib.check(self.lib.ovn_profile_begin(self._h), "ovn_profile_begin")
 
     def profile_end(self):
         """{kind: (total_ms, launches)} measured with HIP events on the launch stream."""
-        ms = (C.c_double * 8)()
-        cnt = (C.c_int64 * 8)()
+        ms = (C.c_double * len(self.PROFILE_KINDS))()
+        cnt = (C.c_int64 * len(self.PROFILE_KINDS))()
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ovn_profile_end(self._h, ms, cnt), "ovn_profile_end")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}

@@ -28,8 +28,9 @@ REFERENCE_MODEL_CFG = {
     "additional_unsymmetric_layer3a": True,
 }
 
-# Gains found with the fp64 oracle so that leg features are O(1) and overlap logits are spread over
-# roughly [-3, 3] instead of collapsing to sigmoid(0) (Glorot weights alone give logit ~ -0.04 +- 0.005).
+# Gains found with the fp64 oracle so that leg features are O(1) (max ~12) and overlap logits do not collapse to
+# sigmoid(0) (Glorot weights alone give logit ~ -0.04 +- 0.005).  With these gains the logits of the candidate pool
+# sit in about [-0.8, 0.05]: a narrow range -- `make_trained_like_weights` below is the wide-range set.
 _LEG_GAIN = 1.34
 _DENSE_GAIN = 5.0
 _DENSE_BIAS = {1: 1.1, 4: 4.6, 5: 1.7}
@@ -57,6 +58,22 @@ def make_test_weights(channels: int = 4, seed: int = 0, model_cfg: Optional[dict
     w["overlap_output/bias"] = np.array([_DENSE_BIAS.get(channels, 2.0)], np.float32)
     return w
 
+
+
+def make_trained_like_weights(channels: int = 4, seed: int = 7, model_cfg: Optional[dict] = None) -> Dict[str, np.ndarray]:
+    """Second seeded weight set with the dynamic range of a trained network rather than of an initialiser:
+    leg kernels at 1.6 x Glorot (features up to ~50 on un-normalised depth images in metres), O(1) biases
+    (uniform +-0.5) in every layer, Dense kernel at 10 x Glorot, Dense bias +6 -- overlap logits of the candidate
+    pool then span about [-13, 7] (both sigmoid tails and the 0.3 loop-closure threshold region are populated)."""
+    cfg = model_cfg or REFERENCE_MODEL_CFG
+    gains = {l.name: 1.6 for l in W.leg_layers(channels, cfg)}
+    gains.update({"c_conv1": 0.8, "c_conv2": 0.8, "c_conv3": 0.8, "overlap_output": 10.0})
+    w = W.synthetic_weights(channels, cfg, seed=seed, kernel_gain=1.0, bias_scale=0.5, gains=gains)
+    w["overlap_output/bias"] = np.array([6.0], np.float32)
+    return w
+
+
+WEIGHT_SETS = {"glorot": make_test_weights, "trained_like": make_trained_like_weights}
 
 
 def load_fixture_images() -> Dict[str, np.ndarray]:
@@ -99,3 +116,22 @@ def candidate_images(n: int, channels: int = 4, seed: int = 1234, noise_m: float
             d = np.where(valid, np.maximum(d + noise, np.float32(1e-3)), d).astype(np.float32)
         out[i] = stack(d, nm, it, flags)
     return out
+
+
+def sweep_pool_images(pool: int, channels: int = 4, rank: int = 0, fixture: Optional[Dict[str, np.ndarray]] = None,
+                      chunk: int = 128):
+    """The candidate pool of the benchmark's 1-vs-`pool` sweep (BASELINE.json configs[1]) as a generator of
+    (start, images) chunks: `candidate_images` per chunk with distinct seeds and one more column roll per chunk and
+    rank, so that no two candidates of a pool (or of two ranks' pools) are the same scan.  bench.py, the parity test
+    at scale and the script that produced its golden oracle outputs all draw the pool from here."""
+    fx = fixture or load_fixture_images()
+    for s in range(0, pool, chunk):
+        n = min(chunk, pool - s)
+        imgs = candidate_images(n, channels, seed=1234 + 7919 * rank + s, fixture=fx)
+        yield s, np.ascontiguousarray(np.roll(imgs, (s * 37 + rank * 11) % 900, axis=2))
+
+
+def sweep_query_image(channels: int = 4, fixture: Optional[Dict[str, np.ndarray]] = None) -> np.ndarray:
+    """(1, 64, 900, C): the query scan of the benchmark sweep = the first shipped scan, unshifted."""
+    fx = fixture or load_fixture_images()
+    return stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], flags_of(channels))[None]

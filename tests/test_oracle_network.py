@@ -123,3 +123,34 @@ def test_oracle_reproduces_committed_golden(fixture_npz, nn_golden, C):
     fv32 = O.leg_forward(imgs, w, S.REFERENCE_MODEL_CFG, np.float32)
     ov32, yaw32, lg32, _ = O.heads_forward(fv32[pairs[:, 0]], fv32[pairs[:, 1]], w, dtype=np.float32)
     assert np.max(np.abs(ov32 - ov)) < 1e-4 and np.array_equal(yaw32, yaw)
+
+
+def test_delta_head_literal_at_full_size():
+    """One pair through the LITERAL forms at the real size (generateNet.py:45-59 tile + abs on 360 x 360 x 128, then
+    c_conv1 1x15 stride (1,15) linear, c_conv2 15x1 stride (15,1), c_conv3 3x3, Flatten, Dense, :96-114) against the fast
+    oracle: pins the stride-15 pooling semantics (which axis c_conv1 / c_conv2 pool) at 360 x 360 x 128, not only on toys."""
+    rng = np.random.default_rng(17)
+    w = S.make_test_weights(4, seed=0)
+    l = np.maximum(rng.normal(0.2, 1.0, size=(360, 1, 128)), 0)      # (w, h, c) = the leg output with its unit height
+    r = np.maximum(rng.normal(0.2, 1.0, size=(360, 1, 128)), 0)
+    r[40:200] = l[10:170]                                            # partly overlapping content, asymmetric roles
+    diff = O.delta_layer_literal(l, r)                               # (360, 360, 128): [i (left), j (right), c]
+    assert diff.shape == (360, 360, 128)
+    o1 = O.conv2d_valid_literal(diff, w["c_conv1/kernel"], w["c_conv1/bias"], (1, 15), relu=False)
+    o2 = O.conv2d_valid_literal(o1, w["c_conv2/kernel"], w["c_conv2/bias"], (15, 1), relu=True)
+    o3 = O.conv2d_valid_literal(o2, w["c_conv3/kernel"], w["c_conv3/bias"], (1, 1), relu=True)
+    assert o1.shape == (360, 24, 64) and o2.shape == (24, 24, 128) and o3.shape == (22, 22, 256)
+    logit = float(o3.reshape(-1) @ w["overlap_output/kernel"].astype(np.float64).reshape(-1) + w["overlap_output/bias"][0])
+    fl = np.transpose(l, (1, 0, 2))[None]                            # (1, 1, 360, 128)
+    fr = np.transpose(r, (1, 0, 2))[None]
+    ov, lg, inter = O.delta_head_forward(fl, fr, w, return_intermediates=True)
+    np.testing.assert_allclose(inter["o1"], o1, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(inter["o2"], o2, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(inter["o3"], o3, rtol=1e-11, atol=1e-11)
+    assert abs(lg[0] - logit) < 1e-10 and abs(ov[0] - 1.0 / (1.0 + np.exp(-logit))) < 1e-12
+    # the head is NOT symmetric in (l, r): swapping the roles changes the result (SURVEY.md 8a, a7)
+    _, lg_sw = O.delta_head_forward(fr, fl, w)
+    assert abs(lg_sw[0] - lg[0]) > 1e-6
+    # correlation head, literal padded sliding window at full size vs the Gram-diagonal closed form
+    corr = O.correlation_head_forward(fl, fr)
+    np.testing.assert_allclose(corr, O.correlation_literal(fl, fr).reshape(1, 360), rtol=1e-11, atol=1e-9)

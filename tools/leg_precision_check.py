@@ -9,7 +9,7 @@ eng=OvnEngine(64,900,C); eng.load_weights(w,S.REFERENCE_MODEL_CFG)
 imgs=S.candidate_images(6,C,seed=3)
 ref=O.leg_forward(imgs,w,S.REFERENCE_MODEL_CFG,np.float64).reshape(6,360,128)
 x=torch.from_numpy(imgs).cuda()
-for mode in ("f32","bf16x3"):
+for mode in ("f32","f16x3"):
     eng.set_leg_precision(mode)
     fv=eng.leg(x).cpu().numpy()
     print(mode,"rel err vs fp64 oracle", np.max(np.abs(fv-ref))/np.max(np.abs(ref)))

@@ -29,7 +29,7 @@ def main():
     con = sqlite3.connect(os.path.join(src, "stats", "bench_results.db"))
     rows = con.execute("select name,total_calls,total_duration,average,percentage from top_kernels").fetchall()
     lines = ["# rocprofv3 --kernel-trace --stats summary (%s)" % tag, "",
-             "command: `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --accuracy-pairs 0` (durations in us)", "",
+             "command: `python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras` (durations in us)", "",
              "| kernel | calls | total us | avg us | % |", "|---|---|---|---|---|"]
     for name, calls, tot, avg, pct in rows:
         out["kernels"].append({"name": short(name), "calls": calls, "total_us": tot, "avg_us": avg, "pct": pct})
