@@ -50,11 +50,17 @@ __device__ __forceinline__ void split_pair_f16(float d0, float d1, float s, floa
   lo_pk = __builtin_bit_cast(unsigned, l);
 }
 
-// max |output| of a wave -> one atomicMax (|v| orders like its float bits)
+// max |output| of a wave -> at most one atomicMax (|v| orders like its float bits).  Every wave of a launch targets the SAME
+// word and one address serialises at ~90 atomics/us (100 k waves of s_conv1 = 1.2 ms), so a wave first reads the word
+// (L1-bypassing load; a stale, smaller value only costs a redundant atomic) and skips the atomic unless it would raise it:
+// after the first few waves almost all do.
 __device__ __forceinline__ void fold_absmax(float vmax, unsigned* out_max) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(out_max, __float_as_uint(vmax));
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned bits = __float_as_uint(vmax);
+    if (bits > __hip_atomic_load(out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_max, bits);
+  }
 }
 
 // Scaled fp16 hi/lo fragments (f16x3 arithmetic), same fragment order: sw * W = hi + lo, both rounded to nearest.

@@ -204,7 +204,8 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   if (a.out_max) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    if (lane == 0) atomicMax(a.out_max, __float_as_uint(vmax));
+    const unsigned bits = __float_as_uint(vmax);   // skip the atomic unless it raises the word (see fold_absmax, conv_f16x3.hip)
+    if (lane == 0 && bits > __hip_atomic_load(a.out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max, bits);
   }
 }
 

@@ -65,6 +65,7 @@ constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + 2 * (size_t)S * FC 
 constexpr int NWAVE = 8;
 constexpr int TL_ELEMS = NWAVE * 3 * 4 * 64 * 4;   // floats of T per pair in accumulator order [wave][t][nt][lane][r]
 constexpr int A2_ELEMS = G * O1;                   // floats of A2 per right volume [jb][o]
+constexpr int A2_KSPLIT = 8;                       // K slices (workgroups) per right volume in delta_a2_kernel
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -204,22 +205,25 @@ __global__ void delta_prep_w2_f16_kernel(const float* __restrict__ w2, _Float16*
   }
 }
 
-// A2raw[v][jb][o] = sum_{dj,c} R_v[15 jb + dj][c] W1[dj][c][o] for right volume v (v = ridx[b] if ridx else 0), on the fp32
-// matrix cores (v_mfma_f32_16x16x4_f32: an fp32 FMA chain).  One workgroup per volume, wave = (m-tile of 16 jb, n-tile of 16 o):
-// rows 15jb .. 15jb+14 of R are contiguous, so the A operand of output row jb is simply R_v[1920 jb + k].
+// A2raw[v][ksl][jb][o] = partial sums over K slice ksl of sum_{dj,c} R_v[15 jb + dj][c] W1[dj][c][o] for right volume v
+// (v = ridx[b] if ridx else 0), on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an fp32 FMA chain).  Grid (volumes, K slices),
+// wave = (m-tile of 16 jb, n-tile of 16 o): rows 15jb .. 15jb+14 of R are contiguous, so the A operand of output row jb is
+// simply R_v[1920 jb + k].  The slices are summed in a fixed order by delta_prepare_kernel.
 __global__ __launch_bounds__(512) void delta_a2_kernel(const float* __restrict__ feats_r, const int32_t* __restrict__ ridx,
                                                        const float* __restrict__ w1raw, float* __restrict__ a2raw) {
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, ksl = blockIdx.y;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lrow = lane & 15, g = lane >> 4;
   const int mt = wave >> 2, nt = wave & 3;
+  constexpr int KS = K1 / 4 / A2_KSPLIT;   // 60 k-steps of 4 per slice
+  static_assert(K1 % (4 * A2_KSPLIT) == 0 && KS % 4 == 0, "K slices must be whole groups of 4 k-steps");
   const float* R = feats_r + (long long)(ridx ? ridx[b] : 0) * OVN_FEAT_ELEMS;
   const int jb = 16 * mt + lrow;
-  const float* arow = R + (size_t)(jb < G ? jb : G - 1) * K1 + g;
-  const float* bcol = w1raw + (size_t)g * O1 + 16 * nt + lrow;
+  const float* arow = R + (size_t)(jb < G ? jb : G - 1) * K1 + g + 4 * KS * ksl;
+  const float* bcol = w1raw + (size_t)(g + 4 * KS * ksl) * O1 + 16 * nt + lrow;
   f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // independent chains
-#pragma unroll 2
-  for (int ks = 0; ks < K1 / 4; ks += 4) {
+#pragma unroll 3
+  for (int ks = 0; ks < KS; ks += 4) {
 #pragma unroll
     for (int u = 0; u < 4; ++u)
       acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * (ks + u)], bcol[(size_t)4 * (ks + u) * O1], acc[u], 0, 0, 0);
@@ -228,18 +232,36 @@ __global__ __launch_bounds__(512) void delta_a2_kernel(const float* __restrict__
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 16 * mt + 4 * g + r;
-    if (row < G) a2raw[(size_t)b * A2_ELEMS + row * O1 + 16 * nt + lrow] = s[r];
+    if (row < G) a2raw[((size_t)b * A2_KSPLIT + ksl) * A2_ELEMS + row * O1 + 16 * nt + lrow] = s[r];
   }
 }
 
-// Per pair: value range of both volumes -> shift c and the power-of-two scales; L packed into P words; T = b1 + (L + c) Ws on
-// the fp32 matrix cores, stored pre-scaled by -(sa sw1)/2 in the main kernel's accumulator order; A2 likewise (from A2raw).
-// scales[2 pair] = {sa, 1/(sa sw1), s1, 1/(s1 sw2)}, scales[2 pair + 1] = {c sa, ...}.  o2max[pair] = 0.
+// WsP[ks(4)][nt(4)][hl(2)][lane(64)][e(8)]: sws * Ws[c = 32 ks + 8 (lane>>4) + e][o = 16 nt + (lane&15)], Ws = W1 summed over its taps
+__global__ void delta_prep_ws_f16_kernel(const float* __restrict__ w1sum, _Float16* __restrict__ wsp, float sws) {
+  const int total = 4 * 4 * 64 * 8;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 7;
+    const int lane = (idx >> 3) & 63;
+    const int nt = (idx >> 9) & 3;
+    const int ks = idx >> 11;
+    _Float16 hi, lo;
+    split_f16(sws * w1sum[(32 * ks + 8 * (lane >> 4) + e) * O1 + 16 * nt + (lane & 15)], hi, lo);
+    const size_t base = (((size_t)ks * 4 + nt) * 2) * 512 + lane * 8 + e;
+    wsp[base] = hi;
+    wsp[base + 512] = lo;
+  }
+}
+
+// Per pair: value range of both volumes -> shift c and the power-of-two scales; then ONE pass over L in MFMA A-fragment order:
+// pack to P words (the main kernel's operand), and T = b1 + (L + c) Ws from those very words on the fp16 matrix cores (3-term
+// split against the scaled hi/lo fragments of Ws), stored pre-scaled by -(sa sw1)/2 in the main kernel's accumulator order;
+// A2 likewise (sum of delta_a2_kernel's K slices).
+// scales[2 pair] = {sa, 1/(sa sw1), s1, 1/(s1 sw2)}, scales[2 pair + 1] = {c sa, c, span, 0}.  o2max[pair] = 0.
 __global__ __launch_bounds__(512) void delta_prepare_kernel(const float* __restrict__ feats_l, const int32_t* __restrict__ lidx,
                                                             const float* __restrict__ feats_r, const int32_t* __restrict__ ridx,
-                                                            const float* __restrict__ w1sum, const float* __restrict__ w1col,
+                                                            const _Float16* __restrict__ wsp, const float* __restrict__ w1col,
                                                             const float* __restrict__ b1, const float* __restrict__ a2raw,
-                                                            float sw1, float sw2, float w1_colsum, float b1_absmax,
+                                                            float sw1, float sw2, float sws, float w1_colsum, float b1_absmax,
                                                             f32x4* __restrict__ scales, unsigned* __restrict__ o2max,
                                                             unsigned* __restrict__ pl, float* __restrict__ tl, float* __restrict__ a2s) {
   __shared__ float red[2][NWAVE];
@@ -285,35 +307,67 @@ __global__ __launch_bounds__(512) void delta_prepare_kernel(const float* __restr
     scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
     o2max[pair] = 0u;   // running max of the pair's c_conv2 output (float bits; values are >= 0), filled by the main kernel
   }
-  // L -> packed words
-  u32x4* P4 = reinterpret_cast<u32x4*>(pl + (size_t)pair * OVN_FEAT_ELEMS);
-  for (int i = tid; i < OVN_FEAT_ELEMS / 4; i += 512) P4[i] = pack4(L4[i], sa, csa);
-  // A2 of this pair: (A2raw + c wcol) kneg
+  // A2 of this pair: (sum of the K slices of A2raw + c wcol) kneg
   {
-    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_ELEMS;
+    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_KSPLIT * A2_ELEMS;
     float* dst = a2s + (size_t)pair * A2_ELEMS;
-    for (int i = tid; i < A2_ELEMS; i += 512) dst[i] = (src[i] + c * w1col[i & (O1 - 1)]) * kneg;
+    for (int i = tid; i < A2_ELEMS; i += 512) {
+      float v = src[i];
+#pragma unroll
+      for (int k = 1; k < A2_KSPLIT; ++k) v += src[(size_t)k * A2_ELEMS + i];
+      dst[i] = (v + c * w1col[i & (O1 - 1)]) * kneg;
+    }
   }
-  // T: wave w, row tiles 3w .. 3w+2, all four n-tiles; K = 128 in 32 steps of 4
+  // L: wave w, row tiles 3w .. 3w+2.  A lane owns row lrow of the tile and channels 32 ks + 8 g .. + 7 of each 32-channel step.
+  unsigned* P = pl + (size_t)pair * OVN_FEAT_ELEMS;
   float* tdst = tl + (size_t)pair * TL_ELEMS + (size_t)wave * (3 * 4 * 64 * 4) + lane * 4;
+  const float inv_t = 1.0f / (sa * sws);
 #pragma unroll 1
   for (int t = 0; t < 3; ++t) {
     const int i = 48 * wave + 16 * t + lrow;
-    const float* arow = Lf + (size_t)(i < FW ? i : FW - 1) * FC + g;
     f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 4
-    for (int ks = 0; ks < FC / 4; ++ks) {
-      const float a = arow[4 * ks];
-      const float* brow = w1sum + (size_t)(4 * ks + g) * O1 + lrow;
+    if (16 * (3 * wave + t) < FW) {   // wave-uniform: the 24th row tile does not exist
+      u32x4 w0[4], w1[4];
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, brow[16 * nt], acc[nt], 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        if (i < FW) {
+          const float* src = Lf + (size_t)i * FC + 32 * ks + 8 * g;
+          w0[ks] = pack4(*reinterpret_cast<const f32x4*>(src), sa, csa);
+          w1[ks] = pack4(*reinterpret_cast<const f32x4*>(src + 4), sa, csa);
+          *reinterpret_cast<u32x4*>(P + (size_t)i * FC + 32 * ks + 8 * g) = w0[ks];
+          *reinterpret_cast<u32x4*>(P + (size_t)i * FC + 32 * ks + 8 * g + 4) = w1[ks];
+        } else {
+          w0[ks] = w1[ks] = (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 h, q;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          h[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x07060302u);
+          q[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x05040100u);
+          h[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x07060302u);
+          q[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x05040100u);
+        }
+        const f16x8 ah = __builtin_bit_cast(f16x8, h), al = __builtin_bit_cast(f16x8, q);
+        const _Float16* wk = wsp + (size_t)ks * (4 * 2 * 512) + lane * 8;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(wk + (nt * 2) * 512), bl = *reinterpret_cast<const f16x8*>(wk + (nt * 2 + 1) * 512);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[nt], 0, 0, 0);
+        }
+      }
     }
+    // the words hold (L + c) sa, so acc / (sa sws) = (L + c) Ws already includes the shift term
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
-      const float add = b1[16 * nt + lrow] + c * w1col[16 * nt + lrow];
+      const float add = b1[16 * nt + lrow];
       f32x4 v;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (48 * wave + 16 * t + 4 * g + r < FW) ? (acc[nt][r] + add) * kneg : 0.0f;
+      for (int r = 0; r < 4; ++r) v[r] = (48 * wave + 16 * t + 4 * g + r < FW) ? fmaf(acc[nt][r], inv_t, add) * kneg : 0.0f;
       *reinterpret_cast<f32x4*>(tdst + (size_t)(t * 4 + nt) * 256) = v;
     }
   }
@@ -321,7 +375,7 @@ __global__ __launch_bounds__(512) void delta_prepare_kernel(const float* __restr
 
 // ABL: timing-only ablations for tools/delta_ablate.py (wrong results; compiled only with -DOVN_ABLATE, product = 0):
 //   1 no epilogue / GEMM2, 2 no L slice reloads, 4 no W1 staging, 8 no chunk barrier, 16 no min/perm VALU, 32 no GEMM1 MFMAs,
-//   64 no pass prologue (R staging, T/A2 loads)
+//   64 no pass prologue (R staging, T/A2 loads), 128 L slice loads issued a chunk ahead instead of at the slice boundary (A/B in one run: 5.55-5.74 vs 5.35-5.42 ms)
 template <int T, int NW, int ABL = 0>
 __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned* __restrict__ pl,
                                                                   const float* __restrict__ tl, const float* __restrict__ a2s,
@@ -365,7 +419,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
     const int i = 16 * T * wave + 16 * t + lrow;
     lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
   }
-  u32x4 la[T][2];
+  u32x4 la[T][2], lb[T][2];   // L words of the current / the next channel slice (ping-pong)
 #define OVN_LOAD_L(DST, SL)                                                                              \
   _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
     if ((ABL & 2) && (SL) != s0) {                                                                       \
@@ -409,9 +463,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
       acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, bl[nt], acc[J][T][nt], 0, 0, 0);         \
   }
   // One channel slice SL (15 MFMA steps = 5 window chunks) with the L slice held in LX.
-#define OVN_SLICE(LX, SL)                                                                                         \
+#define OVN_SLICE(LX, SL, LNEXT, SLNEXT)                                                                          \
   {                                                                                                               \
     for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
+      if ((ABL & 128) && c5 == S / STEPS_PER_CHUNK - 1) OVN_LOAD_L(LNEXT, SLNEXT) /* ablation: a chunk ahead */          \
       const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
       const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
       if (!(ABL & 4)) {                                                                                           \
@@ -454,6 +509,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
       cur ^= 1;                                                                                                   \
       chunk = nxt;                                                                                                \
     }                                                                                                             \
+    if (!(ABL & 128)) OVN_LOAD_L(LNEXT, SLNEXT) /* exposed; prefetching it a chunk ahead (128) slows GEMM2 more */ \
   }
 
   const f32x4* tsrc = reinterpret_cast<const f32x4*>(tl + (size_t)pair * TL_ELEMS + (size_t)wave * (T * 4 * 64 * 4) + lane * 4);
@@ -481,15 +537,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
       }
     __syncthreads();
 
-    // single L register set (the second accumulator set took the ping-pong's registers): each slice load is exposed
-    OVN_SLICE(la, s0)
-    OVN_LOAD_L(la, s1i)
-    OVN_SLICE(la, s1i)
-    OVN_LOAD_L(la, s2i)
-    OVN_SLICE(la, s2i)
-    OVN_LOAD_L(la, s3i)
-    OVN_SLICE(la, s3i)
-    OVN_LOAD_L(la, s0)
+    OVN_SLICE(la, s0, lb, s1i)
+    OVN_SLICE(lb, s1i, la, s2i)
+    OVN_SLICE(la, s2i, lb, s3i)
+    OVN_SLICE(lb, s3i, la, s0)
 
     if (ABL & 1) {   // keep the accumulators alive
       f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -639,7 +690,7 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
          al((size_t)n * TL_ELEMS * sizeof(float)) + al((size_t)n * A2_ELEMS * sizeof(float)) +
-         al((size_t)(per_pair_right ? n : 1) * A2_ELEMS * sizeof(float));
+         al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float));
 }
 
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
@@ -679,9 +730,10 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
-    hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
-    hipLaunchKernelGGL(delta_prepare_kernel, dim3(n), dim3(512), 0, stream, feats_l, lidx, feats_r, ridx, ctx->w1sum, ctx->w1col,
-                       ctx->b1, a2raw, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.w1_colsum, ctx->hs.b1_absmax, scales, o2max, pl, tl, a2s);
+    hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
+    hipLaunchKernelGGL(delta_prepare_kernel, dim3(n), dim3(512), 0, stream, feats_l, lidx, feats_r, ridx,
+                       reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1, a2raw, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.sws,
+                       ctx->hs.w1_colsum, ctx->hs.b1_absmax, scales, o2max, pl, tl, a2s);
   }
   OvnProfScope ps(ctx, OVN_K_DELTA, stream);
 #define OVN_DELTA_LAUNCH(ABLV)                                                                                                  \
@@ -699,7 +751,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     break;
     switch (abl) {
       OVN_ABL_CASE(0) OVN_ABL_CASE(1) OVN_ABL_CASE(2) OVN_ABL_CASE(4) OVN_ABL_CASE(12) OVN_ABL_CASE(16) OVN_ABL_CASE(32)
-      OVN_ABL_CASE(64) OVN_ABL_CASE(67) OVN_ABL_CASE(79) OVN_ABL_CASE(95) OVN_ABL_CASE(111) OVN_ABL_CASE(48)
+      OVN_ABL_CASE(64) OVN_ABL_CASE(67) OVN_ABL_CASE(79) OVN_ABL_CASE(95) OVN_ABL_CASE(128) OVN_ABL_CASE(129) OVN_ABL_CASE(195)
       default: ovn_set_error("OVN_DELTA_ABL=%d not compiled", abl); return OVN_ERR_ARG;
     }
   }
@@ -736,8 +788,21 @@ int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const floa
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1raw, (size_t)K1 * O1 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1sum, (size_t)FC * O1 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1col, (size_t)O1 * sizeof(float)));
+  OVN_HIP_CHECK(hipMalloc(&ctx->wsp_h, (size_t)FC * O1 * 2 * sizeof(_Float16)));
   OVN_HIP_CHECK(hipMemcpyAsync(ctx->w1raw, c1_kernel_dev, (size_t)K1 * O1 * sizeof(float), hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(delta_w1sum_kernel, dim3((FC * O1 + 255) / 256), dim3(256), 0, stream, c1_kernel_dev, ctx->w1sum, ctx->w1col);
+  {   // scale of the tap-summed kernel (up to 15x the largest single weight)
+    float* st = nullptr;
+    OVN_HIP_CHECK(hipMalloc((void**)&st, 2 * sizeof(float)));
+    hipLaunchKernelGGL(delta_wstats_kernel, dim3(1), dim3(256), 0, stream, ctx->w1sum, FC, O1, st);
+    float hws[2];
+    hipError_t e2 = hipMemcpyAsync(hws, st, sizeof(hws), hipMemcpyDeviceToHost, stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream);
+    (void)hipFree(st);
+    OVN_HIP_CHECK(e2);
+    hs->sws = ovn_pow2_scale_for(hws[0]);
+  }
+  hipLaunchKernelGGL(delta_prep_ws_f16_kernel, dim3(32), dim3(256), 0, stream, ctx->w1sum, reinterpret_cast<_Float16*>(ctx->wsp_h), hs->sws);
   hipLaunchKernelGGL(delta_prep_w1_f16_kernel, dim3(240), dim3(256), 0, stream, c1_kernel_dev,
                      reinterpret_cast<_Float16*>(ctx->w1p_h), hs->sw1);
   hipLaunchKernelGGL(delta_prep_w2_f16_kernel, dim3(240), dim3(256), 0, stream, c2_kernel_dev,

@@ -95,6 +95,7 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->w1raw) (void)hipFree(ctx->w1raw);
   if (ctx->w1sum) (void)hipFree(ctx->w1sum);
   if (ctx->w1col) (void)hipFree(ctx->w1col);
+  if (ctx->wsp_h) (void)hipFree(ctx->wsp_h);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->actmax) (void)hipFree(ctx->actmax);
   delete ctx;
@@ -147,7 +148,8 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
     if (ctx->w1raw) (void)hipFree(ctx->w1raw);
     if (ctx->w1sum) (void)hipFree(ctx->w1sum);
     if (ctx->w1col) (void)hipFree(ctx->w1col);
-    ctx->w1p_h = ctx->w2p_h = nullptr;
+    if (ctx->wsp_h) (void)hipFree(ctx->wsp_h);
+    ctx->w1p_h = ctx->w2p_h = ctx->wsp_h = nullptr;
     ctx->w1raw = ctx->w1sum = ctx->w1col = nullptr;
     ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
     ctx->head_set = false;

@@ -62,6 +62,7 @@ __host__ __device__ inline float ovn_pow2_scale_for(float m) {
 // static scales / norms of the Delta-head weights (delta_head_f16x3.hip)
 struct OvnHeadScales {
   float sw1 = 1.f, sw2 = 1.f;     // power-of-two scales of the c_conv1 / c_conv2 kernels
+  float sws = 1.f;                // ... of the tap-summed c_conv1 kernel (left-volume linear term)
   float w1_colsum = 0.f;          // max over output channels o of sum |W1[., ., o]|: bound of c_conv1's output per unit input
   float b1_absmax = 0.f;
 };
@@ -102,6 +103,7 @@ struct ovn_ctx {
   float* w1raw = nullptr;  // c_conv1 kernel as registered, [1920][64]: B operand of the right-volume linear term
   float* w1sum = nullptr;  // c_conv1 kernel summed over its 15 taps, [128][64]: B operand of the left-volume linear term
   float* w1col = nullptr;  // [64] column sums of the c_conv1 kernel (shift term)
+  void* wsp_h = nullptr;   // w1sum as scaled hi/lo fp16 fragments
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
   unsigned* actmax = nullptr;   // [32] float bits of max |activation| per leg layer input of the running call (f16x3 scales)

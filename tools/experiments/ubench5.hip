@@ -97,7 +97,29 @@ __global__ __launch_bounds__(256 * W) void k(const float* __restrict__ in, float
       if (MF == 0) { vsum ^= nh; vsum ^= nl; }
     }
     if (VA == 0) __builtin_amdgcn_sched_barrier(0);
-    if (MF == 1) {
+    if (VA == 2) {
+      // software pipeline: the operands of iteration it+1 are formed (16 VALU) BETWEEN the 12 MFMAs of iteration it
+      u32x4 ch = ah, cl = al;                 // current operands (formed during the previous iteration)
+      make_a_f<F>(l0, l1, n0, n1, one, nh, nl);   // next operands from the prefetched R words
+#pragma unroll
+      for (int m = 0; m < 12; ++m) {
+        const u32x4 a = (m >= 4 && m < 8) ? cl : ch;
+        const u32x4 bb = b[(m < 8 ? 0 : 4) + (m & 3)];
+        acc[m & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, bb), acc[m & 3], 0, 0, 0);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);   // 2 VALU
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+      }
+      ah = nh; al = nl;
+    }
+    if (MF == 1 && VA != 2) {
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         const u32x4 a = (NM == 16) ? ((m & 4) ? nl : nh) : ((m >= 4 && m < 8) ? nl : nh);
@@ -145,6 +167,7 @@ void all(const float* in, float* out) {
   run<1, 1, W, 14>("F14 split + 12 f16 mfma", in, out);
   run<0, 1, W, 15>("F15 min_u32 only (8 VALU)", in, out);
   run<1, 1, W, 15>("F15 + 16 f16 mfma", in, out);
+  run<1, 2, W, 13>("F13 software-pipelined: 12 x (mfma + 1-2 VALU of the next operands)", in, out);
 }
 
 int main() {
