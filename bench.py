@@ -201,7 +201,24 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL prints its version banner on STDOUT (C stdio, fully buffered when stdout is a pipe) at communicator creation; this
+        # program's stdout is ONE JSON line, so fd 1 points at stderr until the first collective has run and C stdio is flushed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     C = args.channels
     pool_total = args.pool_total
@@ -442,6 +459,16 @@ def main():
         ch["note"] = ("spectral form on cached candidate spectra; `frac_of_8TBps` prices SURVEY.md 8d's algorithmic bytes (184,328 B per "
                       "pair), `..._streamed` the 188,420 B the kernel actually reads and writes per pair; ms = HIP events around the launch(es)")
         out["corr_head"] = ch
+        # (5) the drop-in API end to end: streaming sweep through `Infer.infer_multiple` (files on disk -> results on the host)
+        #     next to the same sweep at engine level (device-resident inputs), tools/bench_infer_api.py
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from bench_infer_api import api_sweep, engine_sweep
+        fr = 400
+        es, aps = engine_sweep(fr, C), api_sweep(fr, "multiple")
+        out["infer_api"] = {"frames": fr, "pairs": aps["pairs"], "api_frames_per_s": aps["frames_per_s"], "api_pairs_per_s": aps["pairs_per_s"],
+                            "engine_frames_per_s": es["frames_per_s"], "engine_pairs_per_s": es["pairs_per_s"],
+                            "api_over_engine": aps["frames_per_s"] / es["frames_per_s"],
+                            "step": "frame i: np.load depth+normal .npy, H2D, leg, spectrum, both heads vs ALL i cached frames, results to host"}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, P)
     print(json.dumps(out), flush=True)

@@ -11,7 +11,12 @@
  *     tensor's data_ptr()); the library never takes ownership and never frees caller memory;
  *   - all tensors are float32, channels-last (NHWC), densely packed;
  *   - `stream` is a hipStream_t passed as void* (NULL = the legacy default stream); every call only
- *     ENQUEUES work on it, nothing synchronises unless stated;
+ *     ENQUEUES work on it, nothing synchronises unless stated.  One exception: a context owns ONE scratch
+ *     block that grows on demand; a call that needs more than any earlier call synchronises `stream`
+ *     once to re-allocate it.  All calls on one context must therefore be issued on one stream at a time
+ *     (two streams would race on the scratch);
+ *   - every entry point selects the context's device for its own duration and restores the caller's
+ *     current HIP device before it returns;
  *   - return value 0 = success, non-zero = error, message via ovn_last_error() (thread-local);
  *   - one context per GPU per process; calls on one context are not re-entrant (the reference object
  *     is not thread-safe either: mutable feature cache, infer.py:114,185).

@@ -30,6 +30,8 @@ void ovn_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// One scratch block per context, grown on demand and never shrunk.  Growing it synchronises `stream` and frees the old block
+// (hipFree waits for the device), so a context must be driven from ONE stream at a time (include/ovn_hip.h says so).
 int ovn_ws_reserve(ovn_ctx* ctx, size_t bytes, hipStream_t stream) {
   if (bytes <= ctx->ws_bytes) return OVN_OK;
   if (ctx->ws) {
@@ -37,6 +39,10 @@ int ovn_ws_reserve(ovn_ctx* ctx, size_t bytes, hipStream_t stream) {
     OVN_HIP_CHECK(hipFree(ctx->ws));
     ctx->ws = nullptr;
     ctx->ws_bytes = 0;
+    ctx->dbg_o2 = ctx->dbg_o3 = nullptr;          // they pointed into the old block
+    ctx->dbg_partial = nullptr;
+    ctx->dbg_o2max = nullptr;
+    ctx->dbg_n = 0;
   }
   const size_t want = bytes + bytes / 8;  // a little headroom so near-equal requests do not thrash
   OVN_HIP_CHECK(hipMalloc(&ctx->ws, want));
@@ -56,7 +62,7 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
   int ndev = 0;
   OVN_HIP_CHECK(hipGetDeviceCount(&ndev));
   OVN_REQUIRE(device_id >= 0 && device_id < ndev, OVN_ERR_ARG, "ovn_create: device %d not present (%d devices)", device_id, ndev);
-  OVN_HIP_CHECK(hipSetDevice(device_id));
+  OVN_ON_DEVICE(device_id);
   hipDeviceProp_t prop;
   OVN_HIP_CHECK(hipGetDeviceProperties(&prop, device_id));
   OVN_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, OVN_ERR_STATE,
@@ -79,7 +85,7 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
 
 int ovn_destroy(ovn_ctx* ctx) {
   if (!ctx) return OVN_OK;
-  (void)hipSetDevice(ctx->device);
+  OVN_ON_DEVICE(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& l : ctx->leg) ovn_conv_release(&l);
   ovn_conv_release(&ctx->c2);
@@ -110,7 +116,7 @@ int ovn_add_leg_layer(ovn_ctx* ctx, const char* name, const float* kernel_dev, c
   OVN_REQUIRE(!ctx->finalized, OVN_ERR_STATE, "ovn_add_leg_layer(%s): context already finalized", name);
   const int expect_cin = ctx->leg.empty() ? ctx->in_c : ctx->leg.back().cout;
   OVN_REQUIRE(cin == expect_cin, OVN_ERR_ARG, "ovn_add_leg_layer(%s): cin=%d but previous layer produces %d", name, cin, expect_cin);
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   OvnConvLayer L;
   L.name = name;
   L.kh = kh;
@@ -134,7 +140,7 @@ int ovn_add_leg_layer(ovn_ctx* ctx, const char* name, const float* kernel_dev, c
 int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const float* c2k, const float* c2b,
                          const float* c3k, const float* c3b, const float* dk, const float* db, void* stream_) {
   OVN_REQUIRE(ctx && c1k && c1b && c2k && c2b && c3k && c3b && dk && db, OVN_ERR_ARG, "ovn_set_head_weights: NULL argument");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   hipStream_t stream = (hipStream_t)stream_;
   {  // drop whatever an earlier (possibly half-failed) call left behind
     ovn_conv_release(&ctx->c2);
@@ -217,7 +223,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
   OVN_REQUIRE(n >= 0, OVN_ERR_ARG, "ovn_leg: n < 0");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(images_dev && features_dev, OVN_ERR_ARG, "ovn_leg: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   hipStream_t stream = (hipStream_t)stream_;
   // largest intermediate activation per scan decides the ping-pong buffer size
   size_t max_act = 0;
@@ -274,7 +280,7 @@ int ovn_corr_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const
   OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_corr_head: bad n");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && yaw, OVN_ERR_ARG, "ovn_corr_head: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   OvnProfScope ps(ctx, OVN_K_CORR, (hipStream_t)stream);
   return ovn_corr_forward(feats_l, lidx, feats_r, ridx, (int)n, yaw, corr, (hipStream_t)stream);
 }
@@ -284,7 +290,7 @@ int ovn_spectrum(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* spectra
   OVN_REQUIRE(n >= 0 && n < (1ll << 24), OVN_ERR_ARG, "ovn_spectrum: bad n");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_dev && spectra_dev, OVN_ERR_ARG, "ovn_spectrum: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   OvnProfScope ps(ctx, OVN_K_SPECTRUM, (hipStream_t)stream);
   return ovn_spectrum_forward(ctx, feats_dev, (int)n, spectra_dev, (hipStream_t)stream);
 }
@@ -295,7 +301,7 @@ int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l, const int32_t* lid
   OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_corr_head_spectral: bad n");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(spec_l && spec_r && yaw, OVN_ERR_ARG, "ovn_corr_head_spectral: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   OvnProfScope ps(ctx, OVN_K_CORR_SPECTRAL, (hipStream_t)stream);
   return ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, (hipStream_t)stream);
 }
@@ -374,7 +380,7 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
   OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_heads: bad n");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, true, (hipStream_t)stream_);
 }
 
@@ -384,7 +390,7 @@ int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, cons
   OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_delta_head: bad n");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && overlap, OVN_ERR_ARG, "ovn_delta_head: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, false, (hipStream_t)stream_);
 }
 
@@ -394,7 +400,7 @@ int ovn_best_match(ovn_ctx* ctx, const float* overlap, const int32_t* yaw, const
   OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_best_match: bad n");
   OVN_REQUIRE(index_offset >= 0 && index_offset + n < (1ll << 31), OVN_ERR_ARG, "ovn_best_match: bad index_offset");
   OVN_REQUIRE(out != nullptr && (n == 0 || overlap != nullptr), OVN_ERR_ARG, "ovn_best_match: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return ovn_best_match_forward(overlap, yaw, ids, (int)n, threshold, (int)index_offset, out, (hipStream_t)stream);
 }
 
@@ -405,7 +411,7 @@ int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_de
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_project: ctx is NULL");
   OVN_REQUIRE(n_scans == 0 || (points_dev || max_points_per_scan == 0), OVN_ERR_ARG, "ovn_project: points is NULL");
   OVN_REQUIRE(n_scans == 0 || offsets_dev, OVN_ERR_ARG, "ovn_project: offsets is NULL");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   OvnProfScope ps(ctx, OVN_K_PROJ, (hipStream_t)stream);
   return ovn_project_forward(ctx, points_dev, offsets_dev, n_scans, max_points_per_scan, proj_h, proj_w, fov_up_deg,
                              fov_down_deg, max_range, range_dev, vertex_dev, intensity_dev, idx_dev, normal_dev,
@@ -418,7 +424,7 @@ int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, i
   OVN_REQUIRE(n_scans >= 0 && proj_h > 0 && proj_w > 0, OVN_ERR_ARG, "ovn_normals: bad sizes");
   if (n_scans == 0) return OVN_OK;
   OVN_REQUIRE(range_dev && vertex_dev && normal_dev, OVN_ERR_ARG, "ovn_normals: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return ovn_normals_forward(range_dev, vertex_dev, n_scans, proj_h, proj_w, normal_dev, (hipStream_t)stream);
 }
 
@@ -430,7 +436,7 @@ int ovn_gt_range_images(ovn_ctx* ctx, const float* points_dev, const int64_t* of
   if (n_scans == 0) return OVN_OK;
   OVN_REQUIRE(offsets_dev && range_dev && (points_dev || max_points_per_scan == 0), OVN_ERR_ARG, "ovn_gt_range_images: NULL buffer");
   OVN_REQUIRE(n_scans <= 65535, OVN_ERR_ARG, "ovn_gt_range_images: at most 65535 scans per call");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return ovn_gt_range_forward(points_dev, offsets_dev, n_scans, max_points_per_scan, ref_poses_dev, inv_cur_pose_dev, proj_h,
                               proj_w, fov_up_deg, fov_down_deg, max_range, range_dev, (hipStream_t)stream);
 }
@@ -440,7 +446,7 @@ int ovn_gt_overlap_counts(ovn_ctx* ctx, const float* ref_ranges_dev, const float
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_gt_overlap_counts: ctx is NULL");
   OVN_REQUIRE(n_scans >= 0 && proj_h > 0 && proj_w > 0, OVN_ERR_ARG, "ovn_gt_overlap_counts: bad sizes");
   OVN_REQUIRE(cur_range_dev && counts_dev && (ref_ranges_dev || n_scans == 0), OVN_ERR_ARG, "ovn_gt_overlap_counts: NULL buffer");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return ovn_gt_count_forward(ref_ranges_dev, cur_range_dev, n_scans, proj_h * proj_w, counts_dev, (hipStream_t)stream);
 }
 
@@ -471,7 +477,7 @@ int ovn_profile_begin(ovn_ctx* ctx) {
 
 int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind) {
   OVN_REQUIRE(ctx && ms_by_kind && launches_by_kind, OVN_ERR_ARG, "ovn_profile_end: NULL argument");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   ctx->prof = false;
   for (int k = 0; k < OVN_K_COUNT; ++k) {
     ms_by_kind[k] = 0.0;
@@ -499,7 +505,7 @@ int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind)
 int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, int w, float* out_dev, void* stream) {
   OVN_REQUIRE(ctx && layer >= 0 && layer < (int)ctx->leg.size(), OVN_ERR_ARG, "ovn_debug_conv: no such leg layer");
   OVN_REQUIRE(in_dev && out_dev && nb >= 0, OVN_ERR_ARG, "ovn_debug_conv: bad buffers");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   int oh = 0, ow = 0;
   if (ctx->leg_mode == 0) return ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
   if (!ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, OVN_ACTMAX_SLOTS * sizeof(unsigned)));
@@ -513,7 +519,7 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream) {
   OVN_REQUIRE(ctx && ctx->dbg_o2 && n >= 0 && n <= ctx->dbg_n, OVN_ERR_STATE,
               "ovn_debug_head_activations: call right after ovn_heads with n <= its (first-chunk) pair count");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   if (o2_dev)
     OVN_HIP_CHECK(hipMemcpyAsync(o2_dev, ctx->dbg_o2, (size_t)n * OVN_G * OVN_G * OVN_C2_OUT * sizeof(float),
                                  hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -529,7 +535,7 @@ int64_t ovn_workspace_bytes(ovn_ctx* ctx) { return ctx ? (int64_t)ctx->ws_bytes 
 
 int ovn_selftest(ovn_ctx* ctx) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_selftest: ctx is NULL");
-  OVN_HIP_CHECK(hipSetDevice(ctx->device));
+  OVN_ON_DEVICE(ctx->device);
   return ovn_mfma_selftest(nullptr);
 }
 

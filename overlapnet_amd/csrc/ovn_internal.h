@@ -32,6 +32,32 @@ void ovn_set_error(const char* fmt, ...);
     }                                  \
   } while (0)
 
+// Selects a context's device for the duration of a C-ABI call and restores the caller's current device afterwards: a
+// process may hold contexts on several GPUs, and a library call must not change which GPU the caller's next allocation
+// or kernel lands on.
+struct OvnDeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit OvnDeviceGuard(int dev) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    if (cur == dev) {
+      ok = true;
+      return;
+    }
+    ok = (hipSetDevice(dev) == hipSuccess);
+    if (ok) prev = cur;
+  }
+  ~OvnDeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  OvnDeviceGuard(const OvnDeviceGuard&) = delete;
+  OvnDeviceGuard& operator=(const OvnDeviceGuard&) = delete;
+};
+#define OVN_ON_DEVICE(dev)                                                             \
+  OvnDeviceGuard ovn_device_guard_(dev);                                               \
+  OVN_REQUIRE(ovn_device_guard_.ok, OVN_ERR_HIP, "cannot select HIP device %d", (int)(dev))
+
 // ---- feature geometry fixed by the reference network ----------------------------------------------
 constexpr int OVN_FEAT_W = 360;   // leg_output_width, config/network.yml:77
 constexpr int OVN_FEAT_C = 128;   // s_conv10 filters, generateNet.py:214

@@ -38,7 +38,8 @@ class OvnEngine:
         self.device = torch.device("cuda", self.device_index)
         self.in_h, self.in_w, self.in_c = int(in_h), int(in_w), int(in_c)
         h = C.c_void_p()
-        _lib.check(self.lib.ovn_create(self.device_index, self.in_h, self.in_w, self.in_c, C.byref(h)), "ovn_create")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_create(self.device_index, self.in_h, self.in_w, self.in_c, C.byref(h)), "ovn_create")
         self._h = h
         self.feat_w = 0
         self._leg_ready = False
@@ -49,7 +50,8 @@ class OvnEngine:
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
-            self.lib.ovn_destroy(self._h)
+            with torch.cuda.device(self.device):   # the C side restores the caller's device too; belt and braces
+                self.lib.ovn_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -111,13 +113,40 @@ class OvnEngine:
         if t.numel() % (FEAT_W * FEAT_C) != 0:
             raise _lib.OvnError("%s is not a stack of 360x128 feature volumes" % what)
 
-    def _idx(self, idx, n: Optional[int]) -> Optional[torch.Tensor]:
+    def _idx(self, idx, n: Optional[int], bound: Optional[int] = None, what: str = "pair index") -> Optional[torch.Tensor]:
+        """Index list -> int32 device tensor.  Host lists / arrays are range-checked ON THE HOST before the upload (no device
+        synchronisation); a tensor that already lives on the device is trusted as is (the caller built it)."""
         if idx is None:
             return None
-        t = torch.as_tensor(idx, dtype=torch.int32).to(self.device).contiguous()
+        if isinstance(idx, torch.Tensor) and idx.device == self.device:
+            t = idx.to(torch.int32).contiguous()
+        else:
+            a = np.ascontiguousarray(idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx).reshape(-1)
+            if a.size and not np.issubdtype(a.dtype, np.integer):
+                if not np.all(a == np.floor(a)):
+                    raise IndexError("%s list holds non-integer values" % what)
+            a = a.astype(np.int64)
+            if bound is not None and a.size and (int(a.min()) < 0 or int(a.max()) >= bound):
+                raise IndexError("%s out of range" % what)
+            t = torch.from_numpy(a.astype(np.int32)).to(self.device)
         if n is not None and t.numel() != n:
             raise _lib.OvnError("index list has %d entries, expected %d" % (t.numel(), n))
         return t
+
+    def _pairs(self, nl: int, nr: int, lidx, ridx, n: Optional[int]):
+        """Shared argument checking of every head entry point: (lidx tensor | None, ridx tensor | None, n)."""
+        li = self._idx(lidx, None, nl, "left pair index")
+        if n is None:
+            n = li.numel() if li is not None else nl
+        n = int(n)
+        if li is not None and li.numel() != n:
+            raise _lib.OvnError("lidx has %d entries, expected %d" % (li.numel(), n))
+        if li is None and n > nl:
+            raise _lib.OvnError("n=%d pairs but only %d left feature volumes" % (n, nl))
+        ri = self._idx(ridx, n, nr, "right pair index")
+        if ri is None and n > 0 and nr < 1:
+            raise _lib.OvnError("the right-hand side holds no feature volume")
+        return li, ri, n
 
     def heads(self, feats_l: torch.Tensor, feats_r: torch.Tensor, lidx=None, ridx=None, n: Optional[int] = None,
               want_logit: bool = False, want_corr: bool = False, spec_l: Optional[torch.Tensor] = None,
@@ -129,21 +158,9 @@ class OvnEngine:
             raise _lib.OvnError("head weights not loaded")
         self._check_feats(feats_l, "feats_l")
         self._check_feats(feats_r, "feats_r")
-        li = self._idx(lidx, None)
-        if n is None:
-            n = li.numel() if li is not None else feats_l.numel() // (FEAT_W * FEAT_C)
-        ri = self._idx(ridx, n)
-        if li is not None and li.numel() != n:
-            raise _lib.OvnError("lidx has %d entries, expected %d" % (li.numel(), n))
         nl = feats_l.numel() // (FEAT_W * FEAT_C)
         nr = feats_r.numel() // (FEAT_W * FEAT_C)
-        if li is None and n > nl:
-            raise _lib.OvnError("n=%d pairs but only %d left feature volumes" % (n, nl))
-        if n > 0:
-            if li is not None and (int(li.min()) < 0 or int(li.max()) >= nl):
-                raise IndexError("left pair index out of range")
-            if ri is not None and (int(ri.min()) < 0 or int(ri.max()) >= nr):
-                raise IndexError("right pair index out of range")
+        li, ri, n = self._pairs(nl, nr, lidx, ridx, n)
         overlap = torch.empty(n, dtype=torch.float32, device=self.device)
         logit = torch.empty(n, dtype=torch.float32, device=self.device) if want_logit else None
         if spec_l is not None or spec_r is not None:
@@ -176,10 +193,7 @@ class OvnEngine:
                   want_corr: bool = False):
         self._check_feats(feats_l, "feats_l")
         self._check_feats(feats_r, "feats_r")
-        li = self._idx(lidx, None)
-        if n is None:
-            n = li.numel() if li is not None else feats_l.numel() // (FEAT_W * FEAT_C)
-        ri = self._idx(ridx, n)
+        li, ri, n = self._pairs(feats_l.numel() // (FEAT_W * FEAT_C), feats_r.numel() // (FEAT_W * FEAT_C), lidx, ridx, n)
         yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
         with torch.cuda.device(self.device):
@@ -207,10 +221,7 @@ class OvnEngine:
                 raise _lib.OvnError("%s must be a contiguous float32 tensor on %s" % (what, self.device))
             if t.numel() % (FEAT_C * self.SPEC_W) != 0:
                 raise _lib.OvnError("%s is not a stack of 128x368 spectra" % what)
-        li = self._idx(lidx, None)
-        if n is None:
-            n = li.numel() if li is not None else spec_l.numel() // (FEAT_C * self.SPEC_W)
-        ri = self._idx(ridx, n)
+        li, ri, n = self._pairs(spec_l.numel() // (FEAT_C * self.SPEC_W), spec_r.numel() // (FEAT_C * self.SPEC_W), lidx, ridx, n)
         yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
         with torch.cuda.device(self.device):

@@ -3,8 +3,14 @@
 Same constructor (a `network.yml` dict), same public methods, attributes, argument meaning, return
 types and error behaviour; the Keras/TensorFlow models behind it are replaced by libovn_hip.so
 (hand-written HIP kernels, C ABI in include/ovn_hip.h).  Differences a caller can observe:
-  * feature volumes additionally stay resident in HBM between calls (`infer_multiple` never
-    re-uploads the cache the way `infer.py:192-193` rebuilds `np.array(self.feature_volumes)`);
+  * feature volumes (and their spectra for the correlation head) stay resident in HBM between calls: `infer_multiple`
+    never re-uploads the cache the way `infer.py:192-193` rebuilds `np.array(self.feature_volumes)`, and
+    `self.feature_volumes` is a list-like VIEW of that device cache that copies a volume to the host only when it is
+    indexed (`len()`, `[i]`, iteration, `np.array()` and `.append()` behave like the reference's list);
+  * arithmetic: fp32 storage and accumulation everywhere; the contractions run on the fp16 matrix cores with a scaled
+    3-term split ("f16x3": 22 significand bits per operand -- measured against an fp64 evaluation this is as accurate as
+    running every contraction in fp32, profiles/r2_parity_1024.json).  `config['precision'] = 'f32'` (optional key, absent
+    from the reference's network.yml) selects bit-for-bit fp32 FMA chains on the fp32 matrix cores at ~1/3 of the speed;
   * `pretrained_weightsfilename` may name a native `.npz` (keys `<layer>/kernel|bias`) besides the
     Keras HDF5 file (read by the built-in `hdf5_lite` parser);
   * `infer_best_match` (extension): `infer_multiple` + demo3's decision taken on the GPU;
@@ -23,6 +29,78 @@ from ._lib import OvnError
 from .engine import FEAT_C, FEAT_W, OvnEngine
 
 _VALID_LEGS = ("360OutputkLegs", "360OutputkLegsFixed")       # generateNet.py:119,222
+
+
+class FeatureVolumeCache(object):
+  """`Infer.feature_volumes`: behaves like the reference's Python list of (1, 360, 128) arrays (infer.py:114,185), but the
+  volumes live in HBM (together with their spectra) and are copied to the host one at a time when indexed."""
+
+  def __init__(self, engine, as_array=False):
+    self._engine = engine
+    self._fv = None        # (capacity, 360, 128) device tensor
+    self._spec = None      # (capacity, 128, 368) device tensor: cached spectra for the correlation head
+    self._n = 0
+    self._as_array = as_array   # after infer_multiple_vs_multiple the reference holds an (n,1,360,128) ndarray (infer.py:220)
+
+  # -- device side ---------------------------------------------------------------------------------
+  def extend_device(self, fv: torch.Tensor) -> None:
+    k = fv.shape[0]
+    if self._fv is None or self._n + k > self._fv.shape[0]:
+      cap = max(1024, 2 * (self._n + k))
+      dev = self._engine.device
+      nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
+      ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
+      if self._n:
+        nf[:self._n].copy_(self._fv[:self._n])
+        ns[:self._n].copy_(self._spec[:self._n])
+      self._fv, self._spec = nf, ns
+    self._fv[self._n:self._n + k].copy_(fv)
+    self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
+    self._n += k
+
+  @property
+  def device_features(self) -> torch.Tensor:
+    return self._fv[:self._n] if self._fv is not None else torch.empty((0, FEAT_W, FEAT_C), device=self._engine.device)
+
+  @property
+  def device_spectra(self) -> torch.Tensor:
+    return self._spec[:self._n] if self._spec is not None else torch.empty((0, FEAT_C, self._engine.SPEC_W), device=self._engine.device)
+
+  # -- list / ndarray behaviour ----------------------------------------------------------------------
+  def __len__(self):
+    return self._n
+
+  @property
+  def shape(self):
+    return (self._n, 1, FEAT_W, FEAT_C)
+
+  def _one(self, i):
+    a = self._fv[i].cpu().numpy()
+    return a.reshape(1, FEAT_W, FEAT_C)
+
+  def __getitem__(self, i):
+    if isinstance(i, slice):
+      return [self._one(j) for j in range(*i.indices(self._n))]
+    i = int(i)
+    if i < 0:
+      i += self._n
+    if not 0 <= i < self._n:
+      raise IndexError('list index out of range')
+    return self._one(i)
+
+  def __iter__(self):
+    for i in range(self._n):
+      yield self._one(i)
+
+  def __array__(self, dtype=None, copy=None):
+    a = self.device_features.cpu().numpy().reshape(self._n, 1, FEAT_W, FEAT_C)
+    return a.astype(dtype) if dtype is not None else a
+
+  def append(self, volume) -> None:
+    """list.append of a host (1, 360, 128) volume, as a caller of the reference could do."""
+    v = torch.from_numpy(np.ascontiguousarray(volume, np.float32).reshape(1, FEAT_W, FEAT_C)).to(self._engine.device)
+    self.extend_device(v)
+
 _VALID_OVERLAP_HEADS = ("DeltaLayerConv1NetworkHead",)         # generateNet.py:64
 _VALID_ORIENTATION_HEADS = ("CorrelationHead",)                # generateNet.py:327
 
@@ -93,11 +171,14 @@ class Infer():
     self.engine = OvnEngine(self.inputShape[0], self.inputShape[1], self.inputShape[2], device=device)
     self.leg = self.engine    # reference: keras.Model (infer.py:101)
     self.head = self.engine   # reference: keras.Model (infer.py:111)
+    self.precision = config.get('precision', 'f16x3')   # extension key, see the module docstring
+    if self.precision not in ('f16x3', 'f32'):
+      raise Exception("config['precision'] must be 'f16x3' or 'f32'")
+    self.engine.set_leg_precision(self.precision)
+    self.engine.set_head_precision(self.precision)
 
-    # previous feature volumes (host list like infer.py:114) + their HBM-resident twin
-    self.feature_volumes = []
-    self._dev_fv: Optional[torch.Tensor] = None   # (capacity, 360, 128) on device
-    self._dev_n = 0
+    # previous feature volumes (infer.py:114): list-like view of the HBM-resident cache
+    self.feature_volumes = FeatureVolumeCache(self.engine)
 
     pretrained_weightsfilename = config['pretrained_weightsfilename']
     if weights is not None:
@@ -114,7 +195,7 @@ class Infer():
     """Channel stacking of ImagePairOverlapOrientationSequence.prepareOneInput (:130-207):
     depth -> normals -> class probabilities -> intensity, raw values."""
     h, w, c = self.inputShape
-    x = np.zeros((len(filenames), h, w, c), dtype=np.float32)
+    x = np.zeros((len(filenames), h, w, c), dtype=np.float32)   # the reference fills a zeros array too (:102)
     root = os.path.join(self.datasetpath, self.seq)
     for i, name in enumerate(filenames):
       ch = 0
@@ -170,22 +251,26 @@ class Infer():
     return fv.cpu().numpy().reshape(len(filenames), 1, FEAT_W, FEAT_C)
 
   # ------------------------------------------------------------------------------------------------
-  def _append_device(self, fv: torch.Tensor) -> None:
-    k = fv.shape[0]
-    if self._dev_fv is None or self._dev_n + k > self._dev_fv.shape[0]:
-      cap = max(1024, 2 * (self._dev_n + k))
-      new = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=self.engine.device)
-      if self._dev_fv is not None and self._dev_n:
-        new[:self._dev_n].copy_(self._dev_fv[:self._dev_n])
-      self._dev_fv = new
-    self._dev_fv[self._dev_n:self._dev_n + k].copy_(fv)
-    self._dev_n += k
+  def _heads_device(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray):
+    """pairs[:,0] -> head-left, pairs[:,1] -> head-right (ImagePairOverlapSequenceFeatureVolume.py:43-47).
+    Delta head on the cached feature volumes, correlation head in its spectral form on the cached spectra; the pair
+    indices are range-checked on the host (no device synchronisation before the launches).  When every pair has the
+    same right-hand volume (the 1-vs-N sweep of `infer_multiple`) the library's 1-vs-N form is used: no right index
+    array, and the query's linear term is evaluated once instead of per pair."""
+    feats, spec = cache.device_features, cache.device_spectra
+    right = pair_indizes[:, 1]
+    if len(right) and np.all(right == right[0]):
+      q = int(right[0])
+      if not 0 <= q < len(cache):
+        raise IndexError('index %d is out of bounds for axis 0 with size %d' % (q, len(cache)))
+      return self.engine.heads(feats, feats[q:q + 1], lidx=pair_indizes[:, 0], spec_l=spec, spec_r=spec[q:q + 1])
+    return self.engine.heads(feats, feats, lidx=pair_indizes[:, 0], ridx=right, spec_l=spec, spec_r=spec)
 
-  def _run_heads(self, feats: torch.Tensor, pair_indizes: np.ndarray):
-    """pairs[:,0] -> head-left, pairs[:,1] -> head-right (ImagePairOverlapSequenceFeatureVolume.py:43-47)."""
-    r = self.engine.heads(feats, feats, lidx=pair_indizes[:, 0], ridx=pair_indizes[:, 1])
-    overlap = r["overlap"].cpu().numpy().reshape(-1, 1)
-    yaw = r["yaw"].cpu().numpy().astype(np.int64)
+  def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray):
+    r = self._heads_device(cache, pair_indizes)
+    res = torch.stack([r["overlap"].view(torch.int32), r["yaw"]]).cpu().numpy()      # ONE device-to-host copy for both
+    overlap = res[0].view(np.float32).reshape(-1, 1)
+    yaw = res[1].astype(np.int64)
     return overlap, yaw
 
   def infer_one(self, filepath1, filepath2):
@@ -201,28 +286,28 @@ class Infer():
     if not os.path.isdir(preprocess_data_folder):
       raise Exception('Please first generate preprocessed input data.')
 
-    fv = self._leg_device(list(self.filenames))
+    pair = FeatureVolumeCache(self.engine)
+    pair.extend_device(self._leg_device(list(self.filenames)))
     indizes = np.zeros((1, 2), dtype=int)
     indizes[0, 0] = 0
     indizes[0, 1] = 1
-    overlap, yaw = self._run_heads(fv, indizes)
+    overlap, yaw = self._run_heads(pair, indizes)
     return overlap[0], yaw
 
   def infer_multiple(self, current_frame_id, reference_frame_id):
     """ Loop closing: current frame vs old frames (infer.py:162-203).  The current frame's feature
         volume is computed and appended (index == frame id); older ones must already be cached. """
     filename = [str(current_frame_id).zfill(6)]
-    fv = self._leg_device(filename)
-    self.feature_volumes.append(fv[0].cpu().numpy().reshape(1, FEAT_W, FEAT_C))
-    self._append_device(fv)
+    self.feature_volumes.extend_device(self._leg_device(filename))
 
     if len(reference_frame_id) > 0:
       pair_indizes = np.zeros((len(reference_frame_id), 2), dtype=int)
       pair_indizes[:, 1] = np.ones(len(reference_frame_id)) * current_frame_id
       pair_indizes[:, 0] = reference_frame_id
-      if pair_indizes.min() < 0 or pair_indizes.max() >= self._dev_n:
-        raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(pair_indizes.max()), self._dev_n))
-      overlap, yaw = self._run_heads(self._dev_fv[:self._dev_n], pair_indizes)
+      n = len(self.feature_volumes)
+      if pair_indizes.min() < 0 or pair_indizes.max() >= n:
+        raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(pair_indizes.max()), n))
+      overlap, yaw = self._run_heads(self.feature_volumes, pair_indizes)
       return overlap.squeeze(), yaw
     else:
       return None
@@ -233,17 +318,18 @@ class Infer():
         Returns (reference frame id, overlap, yaw) or None; caches the current frame like `infer_multiple`. """
     from .engine import decode_match
     filename = [str(current_frame_id).zfill(6)]
-    fv = self._leg_device(filename)
-    self.feature_volumes.append(fv[0].cpu().numpy().reshape(1, FEAT_W, FEAT_C))
-    self._append_device(fv)
+    self.feature_volumes.extend_device(self._leg_device(filename))
     if len(reference_frame_id) == 0:
       return None
     ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
-    if ref.min() < 0 or max(int(ref.max()), int(current_frame_id)) >= self._dev_n:
-      raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(ref.max()), self._dev_n))
-    feats = self._dev_fv[:self._dev_n]
+    n = len(self.feature_volumes)
+    if ref.min() < 0 or max(int(ref.max()), int(current_frame_id)) >= n:
+      raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(ref.max()), n))
+    pair_indizes = np.zeros((len(ref), 2), dtype=np.int64)
+    pair_indizes[:, 0] = ref
+    pair_indizes[:, 1] = int(current_frame_id)
+    r = self._heads_device(self.feature_volumes, pair_indizes)
     ids = torch.from_numpy(ref.astype(np.int32)).to(self.engine.device)
-    r = self.engine.heads(feats, feats, lidx=ids, ridx=np.full(len(ref), int(current_frame_id)))
     return decode_match(self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=ids))
 
   def infer_multiple_vs_multiple(self, file_names, first_idxs, second_idxs):
@@ -252,16 +338,14 @@ class Infer():
     if len(first_idxs) != len(second_idxs):
       raise Exception('Please make sure the first_idxs and second_idxs have the same size.')
     file_names = [os.path.basename(v).replace('.bin', '') for v in file_names]
-    fv = self._leg_device(file_names)
-    self.feature_volumes = fv.cpu().numpy().reshape(len(file_names), 1, FEAT_W, FEAT_C)
-    self._dev_fv = fv
-    self._dev_n = fv.shape[0]
+    self.feature_volumes = FeatureVolumeCache(self.engine, as_array=True)
+    self.feature_volumes.extend_device(self._leg_device(file_names))
 
     if len(second_idxs) > 0:
       pair_indizes = np.zeros((len(second_idxs), 2), dtype=int)
       pair_indizes[:, 1] = first_idxs
       pair_indizes[:, 0] = second_idxs
-      overlap, yaw = self._run_heads(fv, pair_indizes)
+      overlap, yaw = self._run_heads(self.feature_volumes, pair_indizes)
       return overlap.squeeze(), yaw
     else:
       return None

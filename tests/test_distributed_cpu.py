@@ -61,7 +61,7 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [0, 1, 5, 1024])
+@pytest.mark.parametrize("n_total", [0, 1, 5, 1024, 100003])
 def test_gather_world2_gloo(n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

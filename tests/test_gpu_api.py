@@ -1,0 +1,145 @@
+"""GPU (MI355X): the drop-in API rows around the hot path, end to end through the HIP library --
+  * a3: the demo1 drivers gen_depth_data / gen_normal_data / gen_intensity_data (gen_depth_data.py:10-48, gen_normal_data.py:10-46,
+        gen_intensity_data.py:10-43) write the .npy files the reference ships, bit for bit, under enumeration-index names;
+  * f2: `Infer(config)` with `pretrained_weightsfilename` naming a Keras-layout HDF5 file (infer.py:117-120);
+  * f3: the evaluation run of testing.py:207-352 (`evaluate.run_test`) on the real `Infer`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import overlapnet_oracle as O
+from overlapnet_amd import synthetic as S
+from overlapnet_amd import weights as W
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")]
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CFG = S.REFERENCE_MODEL_CFG
+
+
+def _write_sequence(root, fx, n, with_intensity=False):
+    """n frames laid out like demo1 writes them: frame i = fixture scan (i mod 2) rolled by 40 (i // 2) columns."""
+    seq = os.path.join(root, "07")
+    for sub in ("depth", "normal", "intensity"):
+        os.makedirs(os.path.join(seq, sub), exist_ok=True)
+    imgs = []
+    for i in range(n):
+        s, shift = i % 2, 40 * (i // 2)
+        d = np.roll(fx["range_%d" % s], shift, axis=1)
+        nm = np.roll(fx["normal_%d" % s], shift, axis=1)
+        it = np.roll(fx["intensity_%d" % s], shift, axis=1)
+        np.save(os.path.join(seq, "depth", "%06d.npy" % i), d)
+        np.save(os.path.join(seq, "normal", "%06d.npy" % i), nm)
+        np.save(os.path.join(seq, "intensity", "%06d.npy" % i), it)
+        imgs.append(S.stack(d, nm, it, (True, True, with_intensity)))
+    return np.stack(imgs)
+
+
+def _config(root, weightfile="", **extra):
+    cfg = {"model": dict(CFG, inputShape=[64, 900]), "infer_seqs": "07", "data_root_folder": str(root), "use_depth": True,
+           "use_normals": True, "use_class_probabilities": False, "use_class_probabilities_pca": False, "use_intensity": False,
+           "batch_size": 16, "pretrained_weightsfilename": weightfile}
+    cfg.update(extra)
+    return cfg
+
+
+def test_gen_data_drivers_write_the_reference_npy_files(tmp_path, fixture_npz):
+    from overlapnet_amd import preprocess as P
+    scans = tmp_path / "scans"
+    os.makedirs(scans)
+    # file names that differ from the enumeration index: the reference names its outputs by INDEX (gen_depth_data.py:41)
+    fixture_npz["points_0"].astype(np.float32).tofile(scans / "000010.bin")
+    fixture_npz["points_1"].astype(np.float32).tofile(scans / "000025.bin")
+    dst = tmp_path / "dst"
+    os.makedirs(dst)
+    depth = P.gen_depth_data(str(scans), str(dst))
+    normal = P.gen_normal_data(str(scans), str(dst))
+    inten = P.gen_intensity_data(str(scans), str(dst))
+    diffs = {}
+    for i in range(2):
+        for sub, key, ret in (("depth", "range_%d", depth), ("normal", "normal_%d", normal), ("intensity", "intensity_%d", inten)):
+            f = dst / sub / ("%06d.npy" % i)
+            assert f.is_file(), "%s not written under its enumeration index" % f
+            got = np.load(f)
+            ref = fixture_npz[key % i]            # produced by the reference's own utils.py, equal to the .npy files it ships
+            assert got.dtype == np.float32 and got.shape == ref.shape and np.array_equal(got, ret[i])
+            d = got != ref
+            diffs["%s_%d" % (sub, i)] = int(np.count_nonzero(d if d.ndim == 2 else np.any(d, axis=-1)))
+    print("pixels differing from the reference-generated .npy files:", diffs)
+    assert all(v == 0 for v in diffs.values()), diffs
+    assert sorted(os.listdir(dst / "depth")) == ["000000.npy", "000001.npy"]
+    # normalize=True divides by the image maximum (gen_depth_data.py:37-38)
+    os.makedirs(tmp_path / "dst2")
+    dn = P.gen_depth_data(str(scans), str(tmp_path / "dst2"), normalize=True)
+    assert np.array_equal(dn[0], fixture_npz["range_0"] / np.max(fixture_npz["range_0"]))
+    assert np.array_equal(np.load(tmp_path / "dst2" / "depth" / "000000.npy"), dn[0])
+
+
+def test_infer_loads_a_keras_layout_weight_file(tmp_path, fixture_npz):
+    from overlapnet_amd.infer import Infer
+    wfile = os.path.join(G, "keras_layout_full_c4.weight")
+    w = W.load_weights_file(wfile)                 # the framework's own HDF5 reader (pinned against h5py in test_hdf5_lite.py)
+    sums = np.load(os.path.join(G, "keras_layout_full_c4_checksums.npz"))
+    for k in sums.files:                           # checksums written by h5py's side of the generator script
+        assert abs(float(w[k].astype(np.float64).sum()) - sums[k][0]) < 1e-9 and abs(float(np.abs(w[k]).astype(np.float64).sum()) - sums[k][1]) < 1e-9
+    imgs = _write_sequence(tmp_path / "data", fixture_npz, 4)
+    inf = Infer(_config(tmp_path / "data", wfile))
+    ref_fv = O.leg_forward(imgs, w, CFG, np.float64)
+    ov, yaw = inf.infer_one("a/000002.bin", "b/000001.bin")       # l = name2 (frame 1), r = name1 (frame 2)
+    o_ov, o_yaw, _, _ = O.heads_forward(ref_fv[[1]], ref_fv[[2]], w)
+    assert abs(ov[0] - o_ov[0]) < 1e-4 and yaw[0] == o_yaw[0]
+    for i in range(4):
+        res = inf.infer_multiple(i, list(range(i)))
+    o_ov, o_yaw, _, _ = O.heads_forward(ref_fv[[0, 1, 2]], ref_fv[[3, 3, 3]], w)
+    assert np.max(np.abs(res[0] - o_ov)) < 1e-4 and np.array_equal(res[1], o_yaw)
+    # the cache is list-like and lives on the device: indexing copies one volume to the host
+    fvs = inf.feature_volumes
+    assert len(fvs) == 4 and fvs[3].shape == (1, 360, 128) and fvs[-1].dtype == np.float32
+    assert np.max(np.abs(fvs[2][0] - ref_fv[2, 0])) <= 2e-5 * np.max(ref_fv)
+    assert np.array(fvs).shape == (4, 1, 360, 128) and len(list(iter(fvs))) == 4
+    # optional extension key: everything on the fp32 matrix cores
+    inf32 = Infer(_config(tmp_path / "data", wfile, precision="f32", model=dict(CFG, inputShape=[64, 900])))
+    assert inf32.engine.leg_precision == "f32" and inf32.engine.head_precision == "f32"
+    ov32, yaw32 = inf32.infer_one("a/000002.bin", "b/000001.bin")
+    assert abs(ov32[0] - ov[0]) < 2e-5 and yaw32[0] == yaw[0]
+    with pytest.raises(Exception, match="precision"):
+        Infer(_config(tmp_path / "data", wfile, precision="int8", model=dict(CFG, inputShape=[64, 900])))
+    with pytest.raises(Exception, match="weight file not found"):
+        Infer(_config(tmp_path / "data", str(tmp_path / "nope.weight"), model=dict(CFG, inputShape=[64, 900])))
+
+
+def test_evaluation_run_on_the_hip_path(tmp_path, fixture_npz):
+    """testing.py's run: GT pairs from an npz in the demo4 layout -> predictions by the real Infer -> error statistics and
+    validation_results.npz; predictions checked against the oracle wired like testing.py:236-243 (img1 -> left, img2 -> right)."""
+    from overlapnet_amd import evaluate as E
+    from overlapnet_amd.infer import Infer
+    imgs = _write_sequence(tmp_path / "data", fixture_npz, 6)
+    w = S.make_test_weights(4, seed=0)
+    rng = np.random.default_rng(3)
+    pairs = np.array([[0, 1], [2, 0], [3, 3], [5, 2], [1, 4], [4, 4], [0, 5]])
+    gt = np.zeros((len(pairs), 4))
+    gt[:, :2] = pairs
+    gt[:, 2] = rng.uniform(0.0, 1.0, len(pairs))
+    gt[:, 3] = rng.integers(0, 360, len(pairs))
+    gt[2, 2] = gt[5, 2] = 0.95                     # self pairs: overlap above the 0.7 yaw threshold
+    gt[2, 3] = gt[5, 3] = 180
+    seq = np.full((len(pairs), 2), "07", dtype=object)
+    npz = str(tmp_path / "ground_truth.npz")
+    np.savez(npz, overlaps=gt, seq=seq)
+    inf = Infer(_config(tmp_path / "data"), weights=w)
+    stats = E.run_test(inf, [npz], out_dir=str(tmp_path / "out"))
+    res = np.load(tmp_path / "out" / "validation_results.npz")
+    m = res[res.files[0]]
+    assert m.shape == (len(pairs), 4) and np.array_equal(m[:, :2], pairs.astype(float))
+    fv = O.leg_forward(imgs, w, CFG, np.float64)
+    o_ov, o_yaw, _, corr = O.heads_forward(fv[pairs[:, 0]], fv[pairs[:, 1]], w)
+    assert np.max(np.abs(m[:, 2] - o_ov)) < 1e-4
+    assert np.array_equal(m[:, 3].astype(int), np.argmax(corr, axis=1))           # the stored value is the argmax bin (testing.py:343)
+    want = E.error_statistics(o_ov, gt[:, 2], np.argmax(corr, axis=1), gt[:, 3].astype(np.int64))
+    assert stats["n"] == len(pairs) and stats["yaw_n"] == want["yaw_n"] >= 2
+    for k in ("overlap_mae", "overlap_rms", "overlap_max"):
+        assert abs(stats[k] - want[k]) < 1e-4
+    assert stats["yaw_mean_err_deg"] == want["yaw_mean_err_deg"] and stats["yaw_max_err_deg"] == want["yaw_max_err_deg"]
+    assert stats["yaw_max_err_deg"] == 0              # self pairs -> bin 180 exactly

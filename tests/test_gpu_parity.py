@@ -5,7 +5,7 @@ Tolerances (north star: |d overlap| <= 1e-4, exact yaw bin):
     (scaled 3-term fp16 split, fp32 accumulate) alike
   * logit: |d| <= 1e-3 * (1 + |logit|);  overlap: |d| <= 1e-4;  yaw: identical bin unless the oracle's
     own top-2 gap is below 1e-5 relative (reported, not failed)
-  * projection: bit-identical images except <= 8 pixels per scan (float32 trig ulps at bin edges)
+  * projection: bit-identical images on both shipped scans (measured: 0 differing pixels)
 """
 import os
 
@@ -17,7 +17,7 @@ from oracle import overlapnet_oracle as O
 from overlapnet_amd import synthetic as S
 from overlapnet_amd import weights as W
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")]
 
 CFG = S.REFERENCE_MODEL_CFG
 
@@ -289,7 +289,8 @@ def test_projection_against_reference_golden(engines, fixture_npz, scan):
     rng = r["range"][0].cpu().numpy()
     ref = fixture_npz["range_%d" % scan]
     diff = rng != ref
-    assert diff.sum() <= 8, "%d range pixels differ from the reference" % diff.sum()
+    print("scan %d: %d range pixels differ from the reference-generated image" % (scan, diff.sum()))
+    assert diff.sum() == 0, "%d range pixels differ from the reference" % diff.sum()
     same = ~diff
     assert np.array_equal(r["intensity"][0].cpu().numpy()[same], fixture_npz["intensity_%d" % scan][same])
     assert np.array_equal(r["idx"][0].cpu().numpy()[same], fixture_npz["idx_%d" % scan][same])

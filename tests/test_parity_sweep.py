@@ -60,6 +60,7 @@ def _stats(d):
 
 
 @pytest.mark.gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")
 @pytest.mark.parametrize("wset", list(S.WEIGHT_SETS))
 def test_sweep_1024_every_pair_against_oracle(wset):
     from overlapnet_amd.engine import OvnEngine
