@@ -191,11 +191,14 @@ class Infer():
     self.engine.load_weights(w, self._model_cfg)
 
   # ------------------------------------------------------------------------------------------------
-  def _load_inputs(self, filenames: Sequence[str]) -> np.ndarray:
+  def _load_inputs(self, filenames: Sequence[str], out: Optional[np.ndarray] = None) -> np.ndarray:
     """Channel stacking of ImagePairOverlapOrientationSequence.prepareOneInput (:130-207):
     depth -> normals -> class probabilities -> intensity, raw values."""
     h, w, c = self.inputShape
-    x = np.zeros((len(filenames), h, w, c), dtype=np.float32)   # the reference fills a zeros array too (:102)
+    if out is not None:
+      x = out          # caller-provided (pinned) staging buffer; every channel is overwritten below
+    else:
+      x = np.zeros((len(filenames), h, w, c), dtype=np.float32)   # the reference fills a zeros array too (:102)
     root = os.path.join(self.datasetpath, self.seq)
     for i, name in enumerate(filenames):
       ch = 0
@@ -239,9 +242,15 @@ class Infer():
     n = len(filenames)
     out = torch.empty((n, FEAT_W, FEAT_C), dtype=torch.float32, device=self.engine.device)
     bs = max(1, int(self.batch_size))
+    if getattr(self, '_stage', None) is None or self._stage.shape[0] < min(bs, n):
+      # pinned host staging buffer: the channel files are loaded straight into it and go to the device in one asynchronous copy
+      self._stage = torch.empty((min(bs, max(n, 1)),) + tuple(self.inputShape), dtype=torch.float32).pin_memory()
     for s in range(0, n, bs):
-      x = torch.from_numpy(self._load_inputs(filenames[s:s + bs])).to(self.engine.device)
-      self.engine.leg(x, out=out[s:s + x.shape[0]])
+      k = min(bs, n - s)
+      self._load_inputs(filenames[s:s + k], out=self._stage[:k].numpy())
+      x = self._stage[:k].to(self.engine.device, non_blocking=True)
+      self.engine.leg(x, out=out[s:s + k])
+      torch.cuda.current_stream(self.engine.device).synchronize()   # the staging buffer is reused by the next batch
     return out
 
   def create_feature_volumes(self, filenames):
@@ -259,12 +268,15 @@ class Infer():
     array, and the query's linear term is evaluated once instead of per pair."""
     feats, spec = cache.device_features, cache.device_spectra
     right = pair_indizes[:, 1]
+    left = pair_indizes[:, 0]
+    if len(left) and left[0] == 0 and np.array_equal(left, np.arange(len(left))):
+      left = None                                   # candidates 0 .. n-1 in order: no index array to upload
     if len(right) and np.all(right == right[0]):
       q = int(right[0])
       if not 0 <= q < len(cache):
         raise IndexError('index %d is out of bounds for axis 0 with size %d' % (q, len(cache)))
-      return self.engine.heads(feats, feats[q:q + 1], lidx=pair_indizes[:, 0], spec_l=spec, spec_r=spec[q:q + 1])
-    return self.engine.heads(feats, feats, lidx=pair_indizes[:, 0], ridx=right, spec_l=spec, spec_r=spec)
+      return self.engine.heads(feats, feats[q:q + 1], lidx=left, n=len(right), spec_l=spec, spec_r=spec[q:q + 1])
+    return self.engine.heads(feats, feats, lidx=left, ridx=right, n=len(right), spec_l=spec, spec_r=spec)
 
   def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray):
     r = self._heads_device(cache, pair_indizes)

@@ -685,6 +685,260 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
 #undef OVN_SLICE
 #undef OVN_TILE_MFMA
 
+// ---- the same computation as TWO workgroups per CU -------------------------------------------------------------------------
+// 4 waves (one per SIMD) and <= 80 KB of LDS per workgroup, so that two pairs are resident on a CU: each SIMD then holds one
+// wave of either pair, and while one pair is in a phase that leaves the matrix pipe idle (o1 conversion, the latency-bound
+// c_conv2 GEMM, L slice loads, barriers: ~25 % of a pair's time in the one-workgroup kernel above) the other pair's wave
+// has the pipe to itself.  Per workgroup: wave w owns rows 96w .. 96w+95 (6 row tiles) of ONE column group per pass (24
+// passes), the W1 stream goes through a 2 x 8 KB window (one MFMA step per slot, one barrier per step among 4 waves), the o1
+// image holds half of c_conv2's K at a time (di 0..7, then di 8..14: 24 rows x 520 fp16 x hi/lo = 49,920 B) and c_conv2 runs
+// in two rounds with wave w owning output columns 32w .. 32w+31.
+constexpr int W4_T = 6;
+constexpr int W4_NW = 4;
+constexpr int W4_KHALF = 8 * O1;                 // 512 K-elements in the first round (7 * 64 = 448 in the second)
+constexpr int W4_O1_STRIDE = W4_KHALF + 8;       // 1040 B per row = 65 16-B slots (odd)
+constexpr size_t W4_LDS_BYTES = 2 * (size_t)G * W4_O1_STRIDE * 2 + (size_t)S * FC * 4 + 2 * STEP_BYTES;   // 73,984
+constexpr int NPASS = G;                         // one column group per pass
+
+template <int ABL = 0>
+__global__ __launch_bounds__(64 * W4_NW, 2) void delta_c12_f16x3_w4_kernel(const unsigned* __restrict__ pl,
+                                                                            const float* __restrict__ tl, const float* __restrict__ a2s,
+                                                                            const float* __restrict__ feats_r,
+                                                                            const int32_t* __restrict__ ridx,
+                                                                            const _Float16* __restrict__ w1p,
+                                                                            const _Float16* __restrict__ w2p,
+                                                                            const float* __restrict__ b2,
+                                                                            const f32x4* __restrict__ scales, float* __restrict__ o2,
+                                                                            unsigned* __restrict__ o2max, int rot, int nsplit) {
+  constexpr int T = W4_T;
+  constexpr int NT_ = 64 * W4_NW;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* o1h = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* o1l = o1h + G * W4_O1_STRIDE;
+  unsigned* rs = reinterpret_cast<unsigned*>(o1l + G * W4_O1_STRIDE);     // packed R rows of the column group
+  unsigned char* wst = reinterpret_cast<unsigned char*>(rs + S * FC);      // 2 x 8 KB window
+
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const unsigned* L = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4 sc = scales[2 * pair];
+  const float sa = sc[0], inv_a1 = sc[1], s1 = sc[2], inv_2 = sc[3];
+  const float csa = scales[2 * pair + 1][0];
+
+  int lrow_off[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = 16 * T * wave + 16 * t + lrow;
+    lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
+  }
+  u32x4 la[T][2];
+#define W4_LOAD_L(SL)                                                                                    \
+  _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
+    if (lrow_off[t] >= 0) {                                                                              \
+      la[t][0] = *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL));                            \
+      la[t][1] = *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                        \
+    } else {                                                                                             \
+      la[t][0] = (u32x4){0u, 0u, 0u, 0u};                                                                \
+      la[t][1] = (u32x4){0u, 0u, 0u, 0u};                                                                \
+    }                                                                                                    \
+  }
+  const int s0 = rot ? ((pair >> 3) & 3) : 0;   // rotated slice order (L2 locality of the W1 stream, see above)
+  W4_LOAD_L(s0)
+
+  // W1 step: 8 KB = [nt(4)][hi/lo][lane][8 fp16]; this thread moves 2 x 16 B of every step.  Walk position v = 0..59 of a pass
+  // is slice (s0 + v / 15) & 3, row dj = v % 15; every pass walks the same 60 steps, so the prefetch simply wraps.
+  // Two register sets: the data of step v+1 sits in P[(v+1)&1] while step v computes, the load of step v+2 is issued at the top
+  // of step v -- two steps (~2 us) for an L2 round trip instead of one.
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  constexpr int PFN = STEP_BYTES / (NT_ * 16);   // 2
+  auto wsrc = [&](int v) {
+    v = (v >= 4 * S) ? v - 4 * S : v;
+    const int k4 = v / S;
+    return w1bytes + (size_t)(((s0 + k4) & 3) * S + (v - k4 * S)) * STEP_BYTES;
+  };
+  f32x4 pf[2][PFN];
+#pragma unroll
+  for (int q = 0; q < PFN; ++q) {
+    pf[0][q] = *reinterpret_cast<const f32x4*>(wsrc(0) + (q * NT_ + tid) * 16);
+    pf[1][q] = *reinterpret_cast<const f32x4*>(wsrc(1) + (q * NT_ + tid) * 16);
+    *reinterpret_cast<f32x4*>(wst + (q * NT_ + tid) * 16) = pf[0][q];
+  }
+  int cur = 0;
+
+  const f32x4* tsrc = reinterpret_cast<const f32x4*>(tl + (size_t)pair * TL_ELEMS + (size_t)wave * (T * 4 * 64 * 4) + lane * 4);
+  const float* a2p = a2s + (size_t)pair * A2_ELEMS + lrow;
+
+  for (int jb = part * NPASS / nsplit; jb < (part + 1) * NPASS / nsplit; ++jb) {
+    __syncthreads();  // previous pass's GEMM2 is done with the o1 image and rs; the window write above is visible
+    for (int i4 = tid; i4 < S * FC / 4; i4 += NT_)
+      *reinterpret_cast<u32x4*>(rs + 4 * i4) = pack4(*reinterpret_cast<const f32x4*>(R + jb * S * FC + 4 * i4), sa, csa);
+    f32x4 acc[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[t][nt] = tsrc[(t * 4 + nt) * 64] + a2p[jb * O1 + 16 * nt];
+    __syncthreads();
+
+#define W4_STEP(V, PSET)                                                                                          \
+  {                                                                                                               \
+    const int k4_ = (V) / S;                                                                                      \
+    const int dj = (V)-k4_ * S;                                                                                   \
+    const int sl = (s0 + k4_) & 3;                                                                                \
+    {                                                                                                             \
+      const unsigned char* src = wsrc((V) + 2);                                                                   \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q) pf[PSET][q] = *reinterpret_cast<const f32x4*>(src + (q * NT_ + tid) * 16); \
+    }                                                                                                             \
+    const unsigned char* wbuf = wst + cur * STEP_BYTES;                                                           \
+    const unsigned* rrow = rs + dj * FC + 32 * g + 8 * sl;                                                        \
+    const u32x4 ra0 = *reinterpret_cast<const u32x4*>(rrow);                                                      \
+    const u32x4 ra1 = *reinterpret_cast<const u32x4*>(rrow + 4);                                                  \
+    f16x8 bh[4], bl[4];                                                                                           \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                            \
+      bh[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                           \
+      bl[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                           \
+    }                                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                               \
+      f16x8 ah, al;                                                                                               \
+      make_a(la[t][0], la[t][1], ra0, ra1, ah, al);                                                               \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[t][nt], 0, 0, 0);                   \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[t][nt], 0, 0, 0);                   \
+      _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                            \
+          acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[t][nt], 0, 0, 0);                   \
+    }                                                                                                             \
+    {                                                                                                             \
+      unsigned char* dstw = wst + (cur ^ 1) * STEP_BYTES;   /* step V+1, loaded during step V-1 */                 \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
+          *reinterpret_cast<f32x4*>(dstw + (q * NT_ + tid) * 16) = pf[(PSET) ^ 1][q];                             \
+    }                                                                                                             \
+    __syncthreads();                                                                                              \
+    cur ^= 1;                                                                                                     \
+    if (dj == S - 1) W4_LOAD_L((sl + 1) & 3) /* next slice (after the fourth: s0 again, for the next pass) */     \
+  }
+#pragma unroll 1
+    for (int v = 0; v < 4 * S; v += 2) {
+      W4_STEP(v, 0)
+      W4_STEP(v + 1, 1)
+    }
+#undef W4_STEP
+
+    // ---- epilogue: o1 = -2 acc / (sa sw1), scaled by s1, as hi/lo fp16 into GEMM2's A layout, half of K at a time ----
+    const float k1 = -2.0f * inv_a1 * s1;   // powers of two: exact
+    f32x4 acc2[2][2];                        // [n-tile][m-tile]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      if (h == 1) __syncthreads();   // round 0 of GEMM2 is done reading the image
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * T * wave + 16 * t + 4 * g + r;
+          const int ib = i / S;
+          const int di = i - ib * S;
+          const int dh = di - 8 * h;
+          if (i < FW && dh >= 0 && dh < 8) {
+            f16x4 h4, l4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              _Float16 hh, ll;
+              split_f16(acc[t][nt][r] * k1, hh, ll);
+              h4[nt] = hh;
+              l4[nt] = ll;
+            }
+            *reinterpret_cast<f16x4*>(o1h + ib * W4_O1_STRIDE + dh * O1 + 4 * lrow) = h4;
+            *reinterpret_cast<f16x4*>(o1l + ib * W4_O1_STRIDE + dh * O1 + 4 * lrow) = l4;
+          }
+        }
+      }
+      __syncthreads();
+      // GEMM2 round h: (24 x K_h) x (K_h x 128), K_0 = 512 (16 k-steps), K_1 = 448 (14); wave w owns columns 32w .. 32w+31
+      const int nks = h ? 14 : 16;
+      const int ksg0 = h ? 16 : 0;            // first global k-step of the round in W2p's K order
+      const int ib0 = lrow;
+      const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;
+      const _Float16* a0h = o1h + ib0 * W4_O1_STRIDE + 8 * g;
+      const _Float16* a0l = o1l + ib0 * W4_O1_STRIDE + 8 * g;
+      const _Float16* a1h = o1h + ib1 * W4_O1_STRIDE + 8 * g;
+      const _Float16* a1l = o1l + ib1 * W4_O1_STRIDE + 8 * g;
+      const _Float16* wcol = w2p + ((size_t)(2 * wave) * 2) * 512 + lane * 8;   // n-tiles 2w, 2w+1: [ks][nt(8)][hl][lane][8]
+      f16x8 wq[3][2][2];   // [slot][n-tile][hi/lo]: two k-steps in flight beside the one being consumed
+#define W4_W2_LOAD(SLOT, KS)                                                                  \
+  {                                                                                           \
+    const _Float16* wk = wcol + (size_t)(ksg0 + (KS)) * (8 * 2 * 512);                         \
+    wq[SLOT][0][0] = *reinterpret_cast<const f16x8*>(wk);                                     \
+    wq[SLOT][0][1] = *reinterpret_cast<const f16x8*>(wk + 512);                               \
+    wq[SLOT][1][0] = *reinterpret_cast<const f16x8*>(wk + 1024);                              \
+    wq[SLOT][1][1] = *reinterpret_cast<const f16x8*>(wk + 1536);                              \
+  }
+#define W4_W2_STEP(SLOT, KS)                                                                  \
+  {                                                                                           \
+    const f16x8 f0h = *reinterpret_cast<const f16x8*>(a0h + 32 * (KS));                       \
+    const f16x8 f0l = *reinterpret_cast<const f16x8*>(a0l + 32 * (KS));                       \
+    const f16x8 f1h = *reinterpret_cast<const f16x8*>(a1h + 32 * (KS));                       \
+    const f16x8 f1l = *reinterpret_cast<const f16x8*>(a1l + 32 * (KS));                       \
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][0][0], acc2[0][0], 0, 0, 0); \
+    acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][0][0], acc2[0][1], 0, 0, 0); \
+    acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][1][0], acc2[1][0], 0, 0, 0); \
+    acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][1][0], acc2[1][1], 0, 0, 0); \
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0l, wq[SLOT][0][0], acc2[0][0], 0, 0, 0); \
+    acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1l, wq[SLOT][0][0], acc2[0][1], 0, 0, 0); \
+    acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0l, wq[SLOT][1][0], acc2[1][0], 0, 0, 0); \
+    acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1l, wq[SLOT][1][0], acc2[1][1], 0, 0, 0); \
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][0][1], acc2[0][0], 0, 0, 0); \
+    acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][0][1], acc2[0][1], 0, 0, 0); \
+    acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][1][1], acc2[1][0], 0, 0, 0); \
+    acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][1][1], acc2[1][1], 0, 0, 0); \
+  }
+      W4_W2_LOAD(0, 0)
+      W4_W2_LOAD(1, 1)
+#pragma unroll 1
+      for (int ks = 0; ks < nks; ks += 3) {   // nks = 16 or 14: the tail steps are guarded
+        if (ks + 2 < nks) W4_W2_LOAD(2, ks + 2)
+        W4_W2_STEP(0, ks)
+        if (ks + 3 < nks) W4_W2_LOAD(0, ks + 3)
+        if (ks + 1 < nks) W4_W2_STEP(1, ks + 1)
+        if (ks + 4 < nks) W4_W2_LOAD(1, ks + 4)
+        if (ks + 2 < nks) W4_W2_STEP(2, ks + 2)
+      }
+#undef W4_W2_LOAD
+#undef W4_W2_STEP
+    }
+    float vmax = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int p = 32 * wave + 16 * nt + lrow;
+      const float bv = b2[p];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ib2 = 16 * mt + 4 * g + r;
+          if (ib2 < G) {
+            const float v = fmaxf(fmaf(acc2[nt][mt][r], inv_2, bv), 0.0f);
+            o2[(((long long)pair * G + ib2) * G + jb) * O2 + p] = v;
+            vmax = fmaxf(vmax, v);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    if (lane == 0) atomicMax(o2max + pair, __float_as_uint(vmax));
+  }
+#undef W4_LOAD_L
+}
 }  // namespace
 
 size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
@@ -737,6 +991,32 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
                        ctx->hs.w1_colsum, ctx->hs.b1_absmax, scales, o2max, pl, tl, a2s);
   }
   OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+  static const int use_w4 = getenv("OVN_DELTA_W4") ? atoi(getenv("OVN_DELTA_W4")) : 1;
+  if (use_w4) {
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_w4_kernel<0>), W4_LDS_BYTES);
+    if (rc) return rc;
+    // two workgroups per CU: 512 resident at a time
+    int ns4 = 1;
+    {
+      double best = 1e30;
+      for (const int d : {1, 2, 3, 4, 6, 8, 12, 24}) {
+        const double cost = (double)(((long long)n * d + 511) / 512) / d;
+        if (cost < best) best = cost;
+      }
+      for (const int d : {1, 2, 3, 4, 6, 8, 12, 24}) {
+        const double cost = (double)(((long long)n * d + 511) / 512) / d;
+        if (cost <= 1.05 * best) {
+          ns4 = d;
+          break;
+        }
+      }
+    }
+    hipLaunchKernelGGL((delta_c12_f16x3_w4_kernel<0>), dim3(n * ns4), dim3(64 * W4_NW), W4_LDS_BYTES, stream, pl, tl, a2s, feats_r, ridx,
+                       reinterpret_cast<const _Float16*>(ctx->w1p_h), reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->c2.bias,
+                       scales, o2, o2max, 1, ns4);
+    OVN_HIP_CHECK(hipGetLastError());
+    return OVN_OK;
+  }
 #define OVN_DELTA_LAUNCH(ABLV)                                                                                                  \
   hipLaunchKernelGGL((delta_c12_f16x3_kernel<3, 8, ABLV>), dim3(n * nsplit), dim3(512), LDS_BYTES, stream, pl, tl, a2s, feats_r, ridx, \
                      reinterpret_cast<const _Float16*>(ctx->w1p_h), reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->c2.bias,  \
