@@ -56,12 +56,18 @@ constexpr int O1 = OVN_C1_OUT;        // 64
 constexpr int O2 = OVN_C2_OUT;        // 128
 constexpr int K1 = S * FC;            // 1920
 constexpr int K2 = S * O1;            // 960
-constexpr int O1_STRIDE = K2 + 8;     // fp16 elements per o1 row in LDS: 1936 B = 121 16-B slots (odd)
+constexpr int KHALF = 8 * O1;         // c_conv2 K per round: 512 (di 0..7), then 448 (di 8..14)
+constexpr int IMG_STRIDE = KHALF + 8; // fp16 elements per o1 image row in LDS: 1040 B = 65 16-B slots (odd)
+constexpr int IMG_ROWS = 2 * G;       // both column groups of a pass: 48 rows = 3 exact m-tiles
 constexpr int STEPS_PER_CHUNK = 3;    // MFMA steps per W1 window chunk; 5 chunks = one 15-step channel slice
 constexpr int NCHUNK = 4 * S / STEPS_PER_CHUNK;   // 20 chunks per column group
 constexpr int STEP_BYTES = 8192;      // [nt(4)][hi/lo][lane(64)][8 fp16]
 constexpr int CHUNK_BYTES = STEPS_PER_CHUNK * STEP_BYTES;
-constexpr size_t LDS_BYTES = 2 * (size_t)G * O1_STRIDE * 2 + 2 * (size_t)S * FC * 4 + 2 * CHUNK_BYTES;
+constexpr size_t IMG_BYTES = 2 * (size_t)IMG_ROWS * IMG_STRIDE * 2;   // hi + lo: 99,840 B
+constexpr size_t RS_BYTES = 2 * (size_t)S * FC * 4;                    // packed R rows of two column groups: 15,360 B
+// the R rows live in the TAIL of the image region: GEMM1 reads them, the epilogue overwrites them (GEMM1 is done by then)
+constexpr size_t LDS_BYTES = IMG_BYTES + 2 * CHUNK_BYTES;
+static_assert(RS_BYTES <= IMG_BYTES, "the R rows alias the image tail");
 constexpr int NWAVE = 8;
 constexpr int TL_ELEMS = NWAVE * 3 * 4 * 64 * 4;   // floats of T per pair in accumulator order [wave][t][nt][lane][r]
 constexpr int A2_ELEMS = G * O1;                   // floats of A2 per right volume [jb][o]
@@ -388,10 +394,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
                                                                   unsigned* __restrict__ o2max, int rot, int nsplit) {
   static_assert(T == 3 && NW == NWAVE, "T is stored for 8 waves x 3 row tiles");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  _Float16* o1h = reinterpret_cast<_Float16*>(smem_raw);
-  _Float16* o1l = o1h + G * O1_STRIDE;
-  unsigned* rs = reinterpret_cast<unsigned*>(o1l + G * O1_STRIDE);       // packed R rows of the two column groups
-  unsigned char* wst = reinterpret_cast<unsigned char*>(rs + 2 * S * FC);  // 2 x 24 KB window
+  _Float16* imgh = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* imgl = imgh + IMG_ROWS * IMG_STRIDE;
+  unsigned* rs = reinterpret_cast<unsigned*>(smem_raw + IMG_BYTES - RS_BYTES);   // packed R rows (alias of the image tail)
+  unsigned char* wst = smem_raw + IMG_BYTES;                                      // 2 x 24 KB window
 
   // nsplit > 1 (small sweeps): the 12 column-group passes of a pair are spread over nsplit workgroups, so that a handful of
   // pairs still fills the chip (a pair's latency drops from 1.4 ms to 1.4 / nsplit ms; no work is duplicated)
@@ -516,7 +522,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
   const float* a2p = a2s + (size_t)pair * A2_ELEMS + lrow;
 
   for (int jb2 = part * (G / 2) / nsplit; jb2 < (part + 1) * (G / 2) / nsplit; ++jb2) {
-    __syncthreads();  // previous pass's GEMM2 is done with o1h/o1l and rs; W window write above is visible
+    __syncthreads();  // previous pass's GEMM2 is done with the o1 image (whose tail the R rows alias); W window write above is visible
     if (!(ABL & 64))
     for (int i4 = tid; i4 < 2 * S * FC / 4; i4 += NT_)
       *reinterpret_cast<u32x4*>(rs + 4 * i4) = pack4(*reinterpret_cast<const f32x4*>(R + jb2 * 2 * S * FC + 4 * i4), sa, csa);
@@ -553,130 +559,104 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
       if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 123.456f) o2[tid] = sacc[0];
       continue;
     }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-    const int jb = 2 * jb2 + j;
-    if (j == 1) __syncthreads();  // GEMM2 of the first group is done with the o1 image
-    // o1 = -2 acc / (sa sw1), scaled by s1 -> LDS as hi/lo fp16 in GEMM2's A layout (K order k' = di*64 + 4*lrow + nt, see the
-    // W2 prep kernel).  C/D: lane holds column lrow of every n-tile, rows 4g..4g+3: one 8-byte store for the 4 hi parts, one
-    // for the lo parts.
+    // ---- epilogue + c_conv2 for BOTH column groups at once, half of c_conv2's K at a time ----
+    // o1 = -2 acc / (sa sw1), scaled by s1, goes to LDS as hi/lo fp16 in GEMM2's A layout: image row m = 24 j + ib (48 rows = 3
+    // exact m-tiles), K order k' = dh*64 + 4*lrow + nt within the half (dh = di for di < 8, di - 8 above; see the W2 prep
+    // kernel).  48 rows x (512 + 8) x hi/lo = 99,840 B: the o1 region plus the R-word rows behind it, which GEMM1 is done with.
+    // One W2 fragment fetch and one barrier sequence then serve both groups, and no MFMA row is padding (2 x 2 m-tiles of 16 for
+    // 2 x 24 rows were 25 % padding; W2 was fetched once per group).
     {
       const float k1 = -2.0f * inv_a1 * s1;   // powers of two: exact
+      f32x4 acc2t[3][3];                       // [m-tile][split term]: nine independent MFMA chains
 #pragma unroll
-      for (int t = 0; t < T; ++t) {
+      for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 16 * T * wave + 16 * t + 4 * g + r;
-          if (i < FW) {
-            const int ib = i / S;
-            const int di = i - ib * S;
-            f16x4 h4, l4;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-              _Float16 h, l;
-              split_f16(acc[j][t][nt][r] * k1, h, l);
-              h4[nt] = h;
-              l4[nt] = l;
-            }
-            *reinterpret_cast<f16x4*>(o1h + ib * O1_STRIDE + di * O1 + 4 * lrow) = h4;
-            *reinterpret_cast<f16x4*>(o1l + ib * O1_STRIDE + di * O1 + 4 * lrow) = l4;
-          }
-        }
-      }
-    }
-    __syncthreads();
-
-    // GEMM2 (24 x 960) x (960 x 128): wave w owns output columns 16w..16w+15 for BOTH 16-row m-tiles, so every
-    // W2 fragment is fetched from L2 by exactly one wave of the workgroup (491 KB per column group, not 2x that).
-    {
-      const int ib0 = lrow;                                   // m-tile 0: rows 0..15
-      const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;  // m-tile 1: rows 16..23 (+ 8 padding rows)
-      const _Float16* a0h = o1h + ib0 * O1_STRIDE + 8 * g;
-      const _Float16* a0l = o1l + ib0 * O1_STRIDE + 8 * g;
-      const _Float16* a1h = o1h + ib1 * O1_STRIDE + 8 * g;
-      const _Float16* a1l = o1l + ib1 * O1_STRIDE + 8 * g;
-      const _Float16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;
-      // one accumulator per (m-tile, split term): six independent MFMA chains per k-step instead of two -- with only two
-      // accumulators every MFMA waited on the one issued two before it (this wave's whole GEMM2 is 2 x 1 tiles)
-      f32x4 acc2t[2][3];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) acc2t[mt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int ks0 = rot ? 6 * ((pair >> 3) % 5) : 0;  // rotated start of the W2 walk, same reason as s0
-      // W2 fragments come straight from L2 (491 KB per column group, no LDS left to stage them): the K walk is
-      // software-pipelined in batches of GB k-steps, batch b+1 in flight while batch b feeds the matrix pipe
-      constexpr int GB = 3, NB = K2 / 32 / GB;
-      static_assert(NB % 2 == 0, "the batch loop is unrolled by two");
-      f16x8 wq0[GB][2], wq1[GB][2];
-      auto ksof = [&](int kk) { const int ks = kk + ks0; return ks >= K2 / 32 ? ks - K2 / 32 : ks; };
-#define OVN_W2_LOAD(DST, B)                                                        \
-  _Pragma("unroll") for (int u = 0; u < GB; ++u) {                                 \
-    const _Float16* wk = wcol + (size_t)ksof((B) * GB + u) * (8 * 2 * 512);        \
-    DST[u][0] = *reinterpret_cast<const f16x8*>(wk);                               \
-    DST[u][1] = *reinterpret_cast<const f16x8*>(wk + 512);                         \
-  }
-// o1 fragments are read from LDS one k-step ahead of the MFMAs that consume them
-#define OVN_W2_READ_A(SLOT, B, U)                                                  \
-  {                                                                                \
-    const int ks_ = ksof((B) * GB + (U));                                          \
-    af[SLOT][0] = *reinterpret_cast<const f16x8*>(a0h + 32 * ks_);                 \
-    af[SLOT][1] = *reinterpret_cast<const f16x8*>(a0l + 32 * ks_);                 \
-    af[SLOT][2] = *reinterpret_cast<const f16x8*>(a1h + 32 * ks_);                 \
-    af[SLOT][3] = *reinterpret_cast<const f16x8*>(a1l + 32 * ks_);                 \
-  }
-#define OVN_W2_COMPUTE(SRC, B)                                                     \
-  {                                                                                \
-    f16x8 af[2][4];                                                                \
-    OVN_W2_READ_A(0, B, 0)                                                         \
-    _Pragma("unroll") for (int u = 0; u < GB; ++u) {                               \
-      if (u + 1 < GB) OVN_W2_READ_A((u + 1) & 1, B, u + 1)                         \
-      __builtin_amdgcn_sched_barrier(0);                                           \
-      acc2t[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][0], SRC[u][0], acc2t[0][0], 0, 0, 0); \
-      acc2t[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][2], SRC[u][0], acc2t[1][0], 0, 0, 0); \
-      acc2t[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][1], SRC[u][0], acc2t[0][1], 0, 0, 0); \
-      acc2t[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][3], SRC[u][0], acc2t[1][1], 0, 0, 0); \
-      acc2t[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][0], SRC[u][1], acc2t[0][2], 0, 0, 0); \
-      acc2t[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[u & 1][2], SRC[u][1], acc2t[1][2], 0, 0, 0); \
-      __builtin_amdgcn_sched_barrier(0);                                           \
-    }                                                                              \
-  }
-      OVN_W2_LOAD(wq0, 0)
+        for (int t3 = 0; t3 < 3; ++t3) acc2t[mt][t3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const _Float16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;   // this wave's n-tile: [ks][nt(8)][hl][lane][8]
 #pragma unroll 1
-      for (int b = 0; b < NB; b += 2) {
-        OVN_W2_LOAD(wq1, b + 1)
-        OVN_W2_COMPUTE(wq0, b)
-        if (b + 2 < NB) {
-          OVN_W2_LOAD(wq0, b + 2)
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1) __syncthreads();   // round 0 of GEMM2 is done reading the image
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * T * wave + 16 * t + 4 * g + r;
+              const int ib = i / S;
+              const int dh = i - ib * S - 8 * h;
+              if (i < FW && dh >= 0 && dh < 8) {
+                f16x4 h4, l4;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                  _Float16 hh, ll;
+                  split_f16(acc[j][t][nt][r] * k1, hh, ll);
+                  h4[nt] = hh;
+                  l4[nt] = ll;
+                }
+                *reinterpret_cast<f16x4*>(imgh + (G * j + ib) * IMG_STRIDE + dh * O1 + 4 * lrow) = h4;
+                *reinterpret_cast<f16x4*>(imgl + (G * j + ib) * IMG_STRIDE + dh * O1 + 4 * lrow) = l4;
+              }
+            }
+          }
+        __syncthreads();
+        // GEMM2 round h: (48 x K_h) x (K_h x 128), K_0 = 512 (16 k-steps), K_1 = 448 (14); W2 fragments straight from L2, one
+        // k-step ahead in flight while the current one feeds the matrix pipe.  (A ring of 3 or 5 fragment pairs in flight, the
+        // first ones issued before the image is written, was measured at 6.4-6.7 ms per launch against 5.5: the longer live
+        // ranges push 100+ more registers into scratch in this phase, where the 96 GEMM1 accumulators are still live.)
+        const int nks = h ? 14 : 16;
+        const _Float16* wk0 = wcol + (size_t)(h ? 16 : 0) * (8 * 2 * 512);
+        const _Float16* ah0 = imgh + lrow * IMG_STRIDE + 8 * g;
+        const _Float16* al0 = imgl + lrow * IMG_STRIDE + 8 * g;
+        f16x8 wq[2][2];
+        wq[0][0] = *reinterpret_cast<const f16x8*>(wk0);
+        wq[0][1] = *reinterpret_cast<const f16x8*>(wk0 + 512);
+#define OVN_W2_STEP(SLOT, KS)                                                                                  \
+  {                                                                                                            \
+    if ((KS) + 1 < nks) {                                                                                      \
+      const _Float16* wk = wk0 + (size_t)((KS) + 1) * (8 * 2 * 512);                                           \
+      wq[(SLOT) ^ 1][0] = *reinterpret_cast<const f16x8*>(wk);                                                 \
+      wq[(SLOT) ^ 1][1] = *reinterpret_cast<const f16x8*>(wk + 512);                                           \
+    }                                                                                                          \
+    f16x8 fh[3], fl[3];                                                                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) {                                                         \
+      fh[mt] = *reinterpret_cast<const f16x8*>(ah0 + mt * 16 * IMG_STRIDE + 32 * (KS));                        \
+      fl[mt] = *reinterpret_cast<const f16x8*>(al0 + mt * 16 * IMG_STRIDE + 32 * (KS));                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                           \
+        acc2t[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[mt], wq[SLOT][0], acc2t[mt][0], 0, 0, 0);     \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                           \
+        acc2t[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[mt], wq[SLOT][0], acc2t[mt][1], 0, 0, 0);     \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                           \
+        acc2t[mt][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[mt], wq[SLOT][1], acc2t[mt][2], 0, 0, 0);     \
+  }
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ks += 2) {   // nks is even
+          OVN_W2_STEP(0, ks)
+          OVN_W2_STEP(1, ks + 1)
         }
-        OVN_W2_COMPUTE(wq1, b + 1)
+#undef OVN_W2_STEP
       }
-#undef OVN_W2_LOAD
-#undef OVN_W2_COMPUTE
-#undef OVN_W2_READ_A
-      f32x4 acc2[2];
-      acc2[0] = (acc2t[0][0] + acc2t[0][1]) + acc2t[0][2];
-      acc2[1] = (acc2t[1][0] + acc2t[1][1]) + acc2t[1][2];
       const int p = 16 * wave + lrow;
       const float bv = b2[p];
       float vmax = 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < 3; ++mt) {
+        const f32x4 a2v = (acc2t[mt][0] + acc2t[mt][1]) + acc2t[mt][2];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int ib2 = 16 * mt + 4 * g + r;
-          if (ib2 < G) {
-            const float v = fmaxf(fmaf(acc2[mt][r], inv_2, bv), 0.0f);
-            o2[(((long long)pair * G + ib2) * G + jb) * O2 + p] = v;
-            vmax = fmaxf(vmax, v);
-          }
+          const int m = 16 * mt + 4 * g + r;          // image row = 24 j + ib
+          const int j = m >= G ? 1 : 0;
+          const int ib2 = m - G * j;
+          const float v = fmaxf(fmaf(a2v[r], inv_2, bv), 0.0f);
+          o2[(((long long)pair * G + ib2) * G + 2 * jb2 + j) * O2 + p] = v;
+          vmax = fmaxf(vmax, v);
         }
       }
       // the pair's max c_conv2 output, for the scale of the fp16 split in c3_dense (non-negative floats order like their bits)
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
       if (lane == 0) atomicMax(o2max + pair, __float_as_uint(vmax));
-    }
     }
   }
 }
