@@ -85,6 +85,33 @@ __global__ void conv_prep_f16_kernel(const float* __restrict__ w, _Float16* __re
   }
 }
 
+// The same for the pixel-major strip kernel (conv_strip.hip, cin 4 / 16): K order (ky, kx padded to 16 taps, c), i.e. K step
+// ks = ky * (cin / 2) + kh covers taps (32 / cin) kh .. of kernel row ky; taps >= kw get zero weights.
+__global__ void conv_prep_f16_pad16_kernel(const float* __restrict__ w, _Float16* __restrict__ wp, int KH, int KW, int Cin, int Cout,
+                                           float sw) {
+  const int NT = Cout / 16;
+  const int ksr = Cin / 2;                 // K steps per kernel row = 16 taps * Cin / 32
+  const int tps = 32 / Cin;
+  const long long total = (long long)KH * ksr * NT * 512;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+    const int s = (int)(e & 7);
+    const int lane = (int)((e >> 3) & 63);
+    const long long t = e >> 9;
+    const int nt = (int)(t % NT);
+    const int ks = (int)(t / NT);
+    const int ky = ks / ksr, kh = ks - ky * ksr;
+    const int kk = 8 * (lane >> 4) + s;                 // position inside the 32-deep step
+    const int tap = tps * kh + kk / Cin, c = kk % Cin;
+    const int n = nt * 16 + (lane & 15);
+    const float v = (tap < KW) ? sw * w[(((long long)ky * KW + tap) * Cin + c) * Cout + n] : 0.0f;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    const long long base = (((long long)ks * NT + nt) * 2) * 512 + lane * 8 + s;
+    wp[base] = hi;
+    wp[base + 512] = lo;
+  }
+}
+
 // out[0] = max |w[i]|, i < n; one workgroup
 __global__ __launch_bounds__(1024) void conv_absmax_kernel(const float* __restrict__ w, long long n, float* __restrict__ out) {
   __shared__ float red[16];
@@ -473,6 +500,12 @@ int ovn_conv_prepare_f16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t
   OVN_HIP_CHECK(hipMalloc(&L->wp_h, elems * sizeof(_Float16)));
   hipLaunchKernelGGL(conv_prep_f16_kernel, dim3(256), dim3(256), 0, stream, kernel_dev, reinterpret_cast<_Float16*>(L->wp_h), K,
                      nkc, L->cout, L->sw_h);
+  if ((L->cin == 4 || L->cin == 16) && L->kw <= 16) {
+    const size_t e16 = (size_t)L->kh * (L->cin / 2) * (L->cout / 16) * 1024;
+    OVN_HIP_CHECK(hipMalloc(&L->wp_h16, e16 * sizeof(_Float16)));
+    hipLaunchKernelGGL(conv_prep_f16_pad16_kernel, dim3(64), dim3(256), 0, stream, kernel_dev, reinterpret_cast<_Float16*>(L->wp_h16),
+                       L->kh, L->kw, L->cin, L->cout, L->sw_h);
+  }
   OVN_HIP_CHECK(hipGetLastError());
   OVN_HIP_CHECK(hipStreamSynchronize(stream));
   return OVN_OK;
@@ -501,7 +534,8 @@ int ovn_absmax_forward(const float* x, long long n, unsigned* out_max, hipStream
 }
 
 int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh_out,
-                           int* ow_out, const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows) {
+                           int* ow_out, const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows,
+                           long long call_nb) {
   OVN_REQUIRE(L.wp_h != nullptr && L.bias != nullptr, OVN_ERR_STATE, "layer %s has no f16x3 weights", L.name.c_str());
   OVN_REQUIRE(in_max != nullptr, OVN_ERR_ARG, "layer %s: f16x3 arithmetic needs the input maximum", L.name.c_str());
   OVN_REQUIRE(h >= L.kh && w >= L.kw, OVN_ERR_ARG, "layer %s: input %dx%d smaller than kernel", L.name.c_str(), h, w);
@@ -533,7 +567,7 @@ int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h
   {  // many scans of s_conv3 / s_conv3a: input strip resident in LDS (conv_strip.hip)
     static const int strip = getenv("OVN_CONV_STRIP") ? atoi(getenv("OVN_CONV_STRIP")) : 1;
     if (strip && !few_rows) {
-      const int took = ovn_conv_strip_try(L, in, nb, h, w, out, in_max, out_max, stream);
+      const int took = ovn_conv_strip_try(L, in, nb, call_nb > nb ? call_nb : nb, h, w, out, in_max, out_max, stream);
       if (took < 0) return -took;
       if (took > 0) return OVN_OK;
     }

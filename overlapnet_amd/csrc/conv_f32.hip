@@ -227,6 +227,8 @@ void ovn_conv_release(OvnConvLayer* L) {
   if (L->bias) (void)hipFree(L->bias);
   if (L->wp_h) (void)hipFree(L->wp_h);
   L->wp_h = nullptr;
+  if (L->wp_h16) (void)hipFree(L->wp_h16);
+  L->wp_h16 = nullptr;
   L->wp = nullptr;
   L->bias = nullptr;
 }

@@ -209,9 +209,183 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   }
 }
 
+// ---- few input channels (s_conv1: 4, s_conv2: 16) --------------------------------------------------------------------------
+// With CIN < 32 an MFMA K step of 32 spans TPS = 32 / CIN consecutive taps kx of one kernel row (KW is padded to 16 taps with
+// zero weights: s_conv1 5 x 15 x 4 -> 10 steps, s_conv2 3 x 15 x 16 -> 24 steps), and the strip is kept PIXEL-major in LDS
+// ([row][pixel][CIN] fp16, hi and lo): the 8 consecutive k of lane group g are then 16 contiguous bytes at pixel
+// SW * m + TPS * kh + 8 g / CIN, channel 8 g % CIN -- the 64 lanes of a fragment read touch 19 (CIN 4, SW 2) / 34 (CIN 16)
+// consecutive 16-byte slots, conflict-free.  The generic implicit-GEMM kernel re-gathers and re-splits every input element for
+// each of the ~19 (s_conv1) / ~22 (s_conv2) output positions that use it and, with only 1 / 2 n-tiles to amortise a split over,
+// ran these two layers at 3 % of the MFMA rate: 46 % of the batched leg's time.
+template <int CIN, int KH, int KW, int SW, int TW, int NT>
+struct SmallCfg {
+  static constexpr int TPS = 32 / CIN;                       // taps per K step
+  static constexpr int KSR = 16 / TPS;                       // K steps per kernel row (taps padded to 16)
+  static constexpr int NK = KH * KSR;
+  static constexpr int PIXA = SW * (TW - 1) + 16 + 8;        // strip pixels per row: last m-tile's last pixel + 16 taps (+ slack)
+  static constexpr int MT = TW / 16;
+  static constexpr int MSPLIT = 8 / NT;
+  static constexpr int MTH = (MT + MSPLIT - 1) / MSPLIT;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)KH * PIXA * CIN * sizeof(_Float16);
+  static_assert(TW % 16 == 0 && 32 % CIN == 0 && CIN % 4 == 0 && KW <= 16, "tile / channel constraints");
+};
+
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT>
+__global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
+  typedef SmallCfg<CIN, KH, KW, SW, TW, NT> C;
+  constexpr int COUT = 16 * NT;
+  constexpr int PIXA = C::PIXA, MTH = C::MTH, NK = C::NK, TPS = C::TPS, KSR = C::KSR;
+  extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
+  _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
+  _Float16* sl = sh + KH * PIXA * CIN;
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
+  const float inv = 1.0f / (s_in * a.sw);
+  const float one = a.one;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+  const int wn = wave % NT;
+  const int wm = wave / NT;
+
+  int bid = blockIdx.x;
+  const int xt = bid % a.XT;
+  bid /= a.XT;
+  const int oy = bid % a.OH;
+  const int b = bid / a.OH;
+  const int x0 = xt * TW;                                      // first output pixel of the tile
+  const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;
+  const int px0 = SW * x0;                                     // first input pixel of the strip
+  const int pixv = (a.W - px0 < PIXA) ? a.W - px0 : PIXA;      // valid input pixels per strip row
+
+  // ---- strip -> LDS, scaled and split once ----
+  {
+    constexpr int Q = CIN / 4;
+    constexpr int TOTAL = KH * PIXA * Q;
+    constexpr int ITERS = (TOTAL + 511) / 512;
+    constexpr int BATCH = 4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int i = tid + (it0 + u) * 512;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (i < TOTAL) {
+          const int row = i / (PIXA * Q);
+          const int r = i - row * (PIXA * Q);
+          const int pix = r / Q;
+          const int c = 4 * (r - pix * Q);
+          if (pix < pixv) v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + px0 + pix) * CIN + c);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int i = tid + (it0 + u) * 512;
+        if (i < TOTAL) {
+          f16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float x0f = v[u][e] * s_in, x1f = v[u][e + 1] * s_in;
+            const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0f, x1f));
+            h[e] = hp[0];
+            h[e + 1] = hp[1];
+            l[e] = (_Float16)__builtin_fmaf(x0f, one, -(float)hp[0]);
+            l[e + 1] = (_Float16)__builtin_fmaf(x1f, one, -(float)hp[1]);
+          }
+          *reinterpret_cast<f16x4*>(sh + 4 * i) = h;           // [row][pix][CIN] is exactly the linear order of i
+          *reinterpret_cast<f16x4*>(sl + 4 * i) = l;
+        }
+      }
+    }
+  }
+
+  // per-lane fragment base: output pixel lrow of the wave's first m-tile, k offset of lane group g
+  const int goff = ((8 * g) / CIN) * CIN + (8 * g) % CIN;       // = 8 g: pixel-major makes (pixel, channel) linear
+  const _Float16* ah_base = sh + (SW * (16 * wm * MTH + lrow)) * CIN + goff;
+  const _Float16* al_base = sl + (SW * (16 * wm * MTH + lrow)) * CIN + goff;
+  f32x4 acc[MTH];
+#pragma unroll
+  for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const _Float16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512) + lane * 8;
+  __syncthreads();  // strip complete
+#pragma unroll
+  for (int ks = 0; ks < NK; ++ks) {
+    const int ky = ks / KSR, kh = ks - ky * KSR;
+    const int toff = (ky * PIXA + TPS * kh) * CIN;
+    const f16x8 bh = *reinterpret_cast<const f16x8*>(wbase + (size_t)ks * (NT * 2 * 512));
+    const f16x8 bl = *reinterpret_cast<const f16x8*>(wbase + (size_t)ks * (NT * 2 * 512) + 512);
+    f16x8 fh[MTH], fl[MTH];
+#pragma unroll
+    for (int i = 0; i < MTH; ++i) {
+      fh[i] = *reinterpret_cast<const f16x8*>(ah_base + toff + i * 16 * SW * CIN);
+      fl[i] = *reinterpret_cast<const f16x8*>(al_base + toff + i * 16 * SW * CIN);
+    }
+#pragma unroll
+    for (int i = 0; i < MTH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bh, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MTH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], bh, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MTH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bl, acc[i], 0, 0, 0);
+  }
+
+  const int n = 16 * wn + lrow;
+  const float bv = a.bias[n];
+  float* orow = a.out + (((long long)b * a.OH + oy) * a.OW + x0) * COUT;
+  float vmax = 0.f;
+#pragma unroll
+  for (int i = 0; i < MTH; ++i) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int p = 16 * (wm * MTH + i) + 4 * g + r;
+      if (p < tw && wm * MTH + i < C::MT) {
+        const float v = fmaxf(fmaf(acc[i][r], inv, bv), 0.0f);
+        orow[(long long)p * COUT + n] = v;
+        vmax = fmaxf(vmax, v);
+      }
+    }
+  }
+  if (a.out_max) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+    const unsigned bits = __float_as_uint(vmax);
+    if (lane == 0 && bits > __hip_atomic_load(a.out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max, bits);
+  }
+}
+
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT>
+int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out, const unsigned* in_max,
+                       unsigned* out_max, hipStream_t stream, bool* took) {
+  typedef SmallCfg<CIN, KH, KW, SW, TW, NT> C;
+  StripArgs a;
+  a.in = in;
+  a.wp = reinterpret_cast<const _Float16*>(L.wp_h16);
+  a.bias = L.bias;
+  a.out = out;
+  a.in_max = in_max;
+  a.out_max = out_max;
+  a.sw = L.sw_h;
+  a.one = 1.0f;
+  a.H = h;
+  a.W = w;
+  a.OH = (h - KH) / SH + 1;
+  a.OW = (w - KW) / SW + 1;
+  a.XT = (a.OW + TW - 1) / TW;
+  const long long wgs = (long long)nb * a.OH * a.XT;
+  *took = call_nb * a.OH * a.XT >= 384;
+  if (!*took) return OVN_OK;
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT>), C::LDS_BYTES);
+  if (rc) return rc;
+  hipLaunchKernelGGL((conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
 template <int CIN, int KH, int SH, int KW, int TW, int NT>
-int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max, unsigned* out_max,
-                 hipStream_t stream, bool* took) {
+int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out, const unsigned* in_max,
+                 unsigned* out_max, hipStream_t stream, bool* took) {
   typedef StripCfg<CIN, KH, KW, TW, NT> C;
   StripArgs a;
   a.in = in;
@@ -228,7 +402,9 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, f
   a.OW = w - KW + 1;
   a.XT = (a.OW + TW - 1) / TW;
   const long long wgs = (long long)nb * a.OH * a.XT;
-  *took = wgs >= 384;                                   // too few workgroups to fill the chip: the generic kernel tiles finer
+  // too few workgroups to fill the chip: the generic kernel tiles finer.  Decided on the scans of the whole CALL, so that every
+  // slice of a call (and with it every scan) takes the same kernel
+  *took = call_nb * a.OH * a.XT >= 384;
   if (!*took) return OVN_OK;
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), C::LDS_BYTES);
   if (rc) return rc;
@@ -242,38 +418,49 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, int h, int w, f
 static int pad_rows(int ow, int tw) { return (ow + tw - 1) / tw * tw - ow; }   // padded output pixels per row with tiles of tw
 
 // Returns 1 when the layer / call was taken (result in out), 0 when the caller should use the generic kernel, < 0 on error.
-int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max,
-                       unsigned* out_max, hipStream_t stream) {
-  if (!(L.sw == 1 && L.relu && L.wp_h != nullptr) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return 0;
+int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out,
+                       const unsigned* in_max, unsigned* out_max, hipStream_t stream) {
+  if (!(L.relu && L.wp_h != nullptr) || (reinterpret_cast<uintptr_t>(in) & 15) != 0) return 0;
   if (h < L.kh || w < L.kw) return 0;
   bool took = false;
   int rc = OVN_OK;
+  if (L.wp_h16 != nullptr) {   // few input channels: pixel-major strips, taps padded to 16
+    if (L.kh == 5 && L.kw == 15 && L.cin == 4 && L.cout == 16 && L.sh == 2 && L.sw == 2)          // s_conv1 at C = 4
+      rc = launch_strip_small<4, 5, 2, 15, 2, 224, 1>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+    else if (L.kh == 3 && L.kw == 15 && L.cin == 16 && L.cout == 32 && L.sh == 2 && L.sw == 1)    // s_conv2
+      rc = launch_strip_small<16, 3, 2, 15, 1, 144, 2>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+    else
+      return 0;
+    if (rc) return -rc;
+    return took ? 1 : 0;
+  }
+  if (L.sw != 1) return 0;
   const int key = ((L.kh * 100 + L.kw) * 1000 + L.cin) * 1000 + L.cout;   // kh, kw, cin, cout
   if (L.kh > 1 && L.sh != 2) return 0;
   if (L.kh == 1 && L.sh != 1) return 0;
   switch (key) {
-    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 208, 4>(L, in, nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3
-    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 135, 4>(L, in, nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3a
+    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 208, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3
+    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 135, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3a
     // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
     case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
-      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<64, 2, 2, 9, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<64, 2, 2, 9, 96, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 9) * 1000 + 128) * 1000 + 128:   // s_conv5-7
-      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 9, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 9, 96, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 7) * 1000 + 128) * 1000 + 128:   // s_conv8
-      rc = (pad_rows(w - 7 + 1, 80) <= pad_rows(w - 7 + 1, 96)) ? launch_strip<128, 1, 1, 7, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 7, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
+      rc = (pad_rows(w - 7 + 1, 80) <= pad_rows(w - 7 + 1, 96)) ? launch_strip<128, 1, 1, 7, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 7, 96, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 5) * 1000 + 128) * 1000 + 128:   // s_conv9
-      rc = (pad_rows(w - 5 + 1, 80) <= pad_rows(w - 5 + 1, 96)) ? launch_strip<128, 1, 1, 5, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 5, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
+      rc = (pad_rows(w - 5 + 1, 80) <= pad_rows(w - 5 + 1, 96)) ? launch_strip<128, 1, 1, 5, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 5, 96, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 3) * 1000 + 128) * 1000 + 128:   // s_conv10
-      rc = (pad_rows(w - 3 + 1, 80) <= pad_rows(w - 3 + 1, 96)) ? launch_strip<128, 1, 1, 3, 80, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<128, 1, 1, 3, 96, 8>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
+      rc = (pad_rows(w - 3 + 1, 80) <= pad_rows(w - 3 + 1, 96)) ? launch_strip<128, 1, 1, 3, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<128, 1, 1, 3, 96, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     default: return 0;
   }

@@ -263,7 +263,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
                                   : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li,
-                                                           last ? nullptr : ctx->actmax + li + 1, stream, n <= 8);
+                                                           last ? nullptr : ctx->actmax + li + 1, stream, n <= 8, n);
       }
       if (rc) return rc;
       cur = dst;

@@ -110,6 +110,8 @@ struct OvnConvLayer {
   float* bias = nullptr;  // [cout] (device)
   void* wp_h = nullptr;   // optional hi/lo fp16 fragments of sw_h * W, [ceil(K/32)][cout/16][2][64][8] (conv_f16x3.hip)
   float sw_h = 1.f;       // power-of-two weight scale of wp_h
+  void* wp_h16 = nullptr; // layers with cin 4 / 16 and kw <= 16: the same fragments in the K order (ky, kx padded to 16, c) of the
+                          // pixel-major strip kernel (conv_strip.hip), [kh * 512 / cin... steps][cout/16][2][64][8]
 };
 
 struct ovn_ctx {
@@ -192,8 +194,9 @@ int ovn_conv_prepare_f16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t
 // out_max: NULL, or a zeroed device word into which max |out| is folded for the next layer.
 // few_rows: the whole call (not just this slice) is a handful of scans -> the split-K kernels may be used; decided by
 // the caller so that every scan of one call takes the same code path
+// call_nb: scans of the whole call (>= nb): the strip kernels are chosen on it, so that every slice takes the same kernels
 int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh, int* ow,
-                           const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows = false);
+                           const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows = false, long long call_nb = 0);
 int ovn_absmax_forward(const float* x, long long n, unsigned* out_max, hipStream_t stream);
 
 // delta_head.hip
@@ -220,8 +223,9 @@ int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* fea
 int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
 // conv_strip.hip: LDS-resident strip kernels for the 3 x KW / stride (2,1) leg layers with 64 outputs (f16x3 mode)
-int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max,
-                       unsigned* out_max, hipStream_t stream);
+// call_nb: scans of the whole call this slice belongs to (kernel choice is per call, not per slice)
+int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out,
+                       const unsigned* in_max, unsigned* out_max, hipStream_t stream);
 
 // c3_dense.hip: c_conv3 + Flatten + Dense fused (f16x3 mode), input patch resident in LDS
 // o2max: the per-pair maxima of o2 left by the f16x3 Delta kernel (scale of the fp16 split)
