@@ -191,50 +191,64 @@ class Infer():
     self.engine.load_weights(w, self._model_cfg)
 
   # ------------------------------------------------------------------------------------------------
-  def _load_inputs(self, filenames: Sequence[str], out: Optional[np.ndarray] = None) -> np.ndarray:
-    """Channel stacking of ImagePairOverlapOrientationSequence.prepareOneInput (:130-207):
-    depth -> normals -> class probabilities -> intensity, raw values."""
+  # ---- inputs: channel stacking of ImagePairOverlapOrientationSequence.prepareOneInput (:130-207), depth -> normals -> class
+  #      probabilities -> intensity, raw values; one pinned, contiguous host buffer per cue, interleaved on the GPU ----
+  def _cue_files(self):
+    """(sub-folder, channels, error label or None) per cue in the reference's channel order (:143-207)."""
+    cues = []
+    if self.use_depth:
+      cues.append(('depth', 1, 'depth'))
+    if self.use_normals:
+      cues.append(('normal', 3, 'normal'))
+    if self.use_class_probabilities:
+      cues.append(('probability_pca', 3, None) if self.use_class_probabilities_pca else ('probability', 20, None))
+    if self.use_intensity:
+      cues.append(('intensity', 1, None))
+    return cues
+
+  @staticmethod
+  def _read_npy_into(path: str, dst: np.ndarray) -> None:
+    """np.load(path) into `dst` without the intermediate array when the file holds exactly dst's dtype / shape (C order);
+    raises IOError like np.load when the file cannot be opened."""
+    with open(path, 'rb') as f:
+      try:
+        version = np.lib.format.read_magic(f)
+        shape, fortran, dtype = (np.lib.format.read_array_header_1_0(f) if version == (1, 0)
+                                 else np.lib.format.read_array_header_2_0(f))
+      except Exception:
+        shape = None
+      if shape is not None and not fortran and dtype == dst.dtype and tuple(shape) == tuple(dst.shape) and dst.flags['C_CONTIGUOUS']:
+        if f.readinto(memoryview(dst).cast('B')) == dst.nbytes:
+          return
+    dst[...] = np.load(path)
+
+  def _inputs_device(self, filenames: Sequence[str]) -> torch.Tensor:
+    """(n,h,w,C) leg input on the device: every cue's files are read straight into a pinned staging buffer (depth (n,h,w),
+    normals (n,h,w,3), ...), copied asynchronously and interleaved by one device-side concatenation (a strided host-side
+    interleave plus a pageable copy cost more than the leg itself for a single frame)."""
     h, w, c = self.inputShape
-    if out is not None:
-      x = out          # caller-provided (pinned) staging buffer; every channel is overwritten below
-    else:
-      x = np.zeros((len(filenames), h, w, c), dtype=np.float32)   # the reference fills a zeros array too (:102)
+    n = len(filenames)
     root = os.path.join(self.datasetpath, self.seq)
-    for i, name in enumerate(filenames):
-      ch = 0
-      if self.use_depth:
-        f = os.path.join(root, 'depth', name + '.npy')
-        try:
-          img = np.load(f)
-        except IOError:
-          raise Exception('Could not read depth image %s' % f)
-        x[i, :, :, ch] = img
-        ch += 1
-      if self.use_normals:
-        f = os.path.join(root, 'normal', name + '.npy')
-        try:
-          img = np.load(f)
-        except IOError:
-          raise Exception('Could not read normal image %s' % f)
-        x[i, :, :, ch:ch + 3] = img
-        ch += 3
-      if self.use_class_probabilities:
-        sub, k = ('probability_pca', 3) if self.use_class_probabilities_pca else ('probability', 20)
+    dev = self.engine.device
+    if getattr(self, '_stage', None) is None or self._stage_n < n:
+      self._stage_n = max(n, 1)
+      self._stage = {sub: torch.empty((self._stage_n, h, w) + ((k,) if k > 1 else ()), dtype=torch.float32).pin_memory()
+                     for sub, k, _ in self._cue_files()}
+    parts = []
+    for sub, k, label in self._cue_files():
+      host = self._stage[sub][:n]
+      hv = host.numpy()
+      for i, name in enumerate(filenames):
         f = os.path.join(root, sub, name + '.npy')
         try:
-          img = np.load(f)
+          self._read_npy_into(f, hv[i])
         except IOError:
-          img = np.load(os.path.join(root, sub, name + '.npz'))
-        x[i, :, :, ch:ch + k] = img
-        ch += k
-      if self.use_intensity:
-        f = os.path.join(root, 'intensity', name + '.npy')
-        try:
-          img = np.load(f)
-        except IOError:
-          img = np.load(os.path.join(root, 'intensity', name + '.npz'))
-        x[i, :, :, ch] = img
-        ch += 1
+          if label is not None:
+            raise Exception('Could not read %s image %s' % (label, f))
+          hv[i] = np.load(os.path.join(root, sub, name + '.npz'))
+      d = host.to(dev, non_blocking=True)
+      parts.append(d if k > 1 else d.unsqueeze(-1))
+    x = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=-1)
     return x
 
   def _leg_device(self, filenames: Sequence[str]) -> torch.Tensor:
@@ -242,15 +256,11 @@ class Infer():
     n = len(filenames)
     out = torch.empty((n, FEAT_W, FEAT_C), dtype=torch.float32, device=self.engine.device)
     bs = max(1, int(self.batch_size))
-    if getattr(self, '_stage', None) is None or self._stage.shape[0] < min(bs, n):
-      # pinned host staging buffer: the channel files are loaded straight into it and go to the device in one asynchronous copy
-      self._stage = torch.empty((min(bs, max(n, 1)),) + tuple(self.inputShape), dtype=torch.float32).pin_memory()
     for s in range(0, n, bs):
       k = min(bs, n - s)
-      self._load_inputs(filenames[s:s + k], out=self._stage[:k].numpy())
-      x = self._stage[:k].to(self.engine.device, non_blocking=True)
+      x = self._inputs_device(filenames[s:s + k])
       self.engine.leg(x, out=out[s:s + k])
-      torch.cuda.current_stream(self.engine.device).synchronize()   # the staging buffer is reused by the next batch
+      torch.cuda.current_stream(self.engine.device).synchronize()   # the staging buffers are reused by the next batch
     return out
 
   def create_feature_volumes(self, filenames):
