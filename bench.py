@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from overlapnet_amd import distributed as D  # noqa: E402
-from overlapnet_amd import synthetic as S  # noqa: E402
+from tools import synthetic as S  # noqa: E402
 from overlapnet_amd.engine import OvnEngine  # noqa: E402
 
 # algorithmic work of the dominant kernel (fused DeltaLayer + c_conv1 + c_conv2), SURVEY.md section 8a row a7:

@@ -430,8 +430,10 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
   _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
     if ((ABL & 2) && (SL) != s0) {                                                                       \
     } else if (lrow_off[t] >= 0) {                                                                              \
-      DST[t][0] = *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL));                           \
-      DST[t][1] = *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                       \
+      DST[t][0] = (ABL & 256) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL)))      \
+                              : *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL));                           \
+      DST[t][1] = (ABL & 256) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4))  \
+                              : *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                       \
     } else {                                                                                             \
       DST[t][0] = (u32x4){0u, 0u, 0u, 0u};                                                               \
       DST[t][1] = (u32x4){0u, 0u, 0u, 0u};                                                               \
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
           acc[0][t][nt] = acc[1][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
           continue;
         }
-        const f32x4 tv = tsrc[(t * 4 + nt) * 64];
+        const f32x4 tv = (ABL & 256) ? __builtin_nontemporal_load(tsrc + (t * 4 + nt) * 64) : tsrc[(t * 4 + nt) * 64];
         acc[0][t][nt] = tv + a2p[(2 * jb2) * O1 + 16 * nt];
         acc[1][t][nt] = tv + a2p[(2 * jb2 + 1) * O1 + 16 * nt];
       }
@@ -649,7 +651,8 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
           const int j = m >= G ? 1 : 0;
           const int ib2 = m - G * j;
           const float v = fmaxf(fmaf(a2v[r], inv_2, bv), 0.0f);
-          o2[(((long long)pair * G + ib2) * G + 2 * jb2 + j) * O2 + p] = v;
+          if (ABL & 256) __builtin_nontemporal_store(v, o2 + (((long long)pair * G + ib2) * G + 2 * jb2 + j) * O2 + p);
+          else o2[(((long long)pair * G + ib2) * G + 2 * jb2 + j) * O2 + p] = v;
           vmax = fmaxf(vmax, v);
         }
       }
@@ -732,7 +735,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     break;
     switch (abl) {
       OVN_ABL_CASE(0) OVN_ABL_CASE(1) OVN_ABL_CASE(2) OVN_ABL_CASE(4) OVN_ABL_CASE(12) OVN_ABL_CASE(16) OVN_ABL_CASE(32)
-      OVN_ABL_CASE(64) OVN_ABL_CASE(67) OVN_ABL_CASE(79) OVN_ABL_CASE(95) OVN_ABL_CASE(128) OVN_ABL_CASE(129) OVN_ABL_CASE(195)
+      OVN_ABL_CASE(64) OVN_ABL_CASE(67) OVN_ABL_CASE(79) OVN_ABL_CASE(95) OVN_ABL_CASE(128) OVN_ABL_CASE(129) OVN_ABL_CASE(195) OVN_ABL_CASE(256) OVN_ABL_CASE(257)
       default: ovn_set_error("OVN_DELTA_ABL=%d not compiled", abl); return OVN_ERR_ARG;
     }
   }

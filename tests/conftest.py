@@ -14,7 +14,7 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session")
 def fixture_npz():
-    from overlapnet_amd import synthetic as S
+    from tools import synthetic as S
     return S.load_fixture_images()
 
 

@@ -16,7 +16,7 @@ import numpy as np
 
 here = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(here)))
-from overlapnet_amd import synthetic as S  # noqa: E402
+from tools import synthetic as S  # noqa: E402
 
 w = S.make_test_weights(4, seed=3)
 q = {k: (np.round(v * 512.0) / 512.0).astype(np.float32) for k, v in w.items()}

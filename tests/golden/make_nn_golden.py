@@ -15,7 +15,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import overlapnet_oracle as O  # noqa: E402
-from overlapnet_amd import synthetic as S  # noqa: E402
+from tools import synthetic as S  # noqa: E402
 
 fx = S.load_fixture_images()
 out = {}

@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import overlapnet_oracle as O  # noqa: E402
-from overlapnet_amd import synthetic as S  # noqa: E402
+from tools import synthetic as S  # noqa: E402
 
 
 def oracle_sweep(pool, channels, weights, log=print):

@@ -68,3 +68,5 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+                # nor the test / bench infrastructure (synthetic inputs, golden fixtures)
+                assert "from tools" not in txt and "import tools" not in txt and "tests/golden" not in txt, f

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from oracle import overlapnet_oracle as O
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd import weights as W
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")]

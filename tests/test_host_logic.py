@@ -6,7 +6,7 @@ import pytest
 
 from overlapnet_amd import evaluate as E
 from overlapnet_amd import lcd
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd import weights as W
 
 

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import overlapnet_oracle as O
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd import weights as W
 
 

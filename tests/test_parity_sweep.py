@@ -18,7 +18,7 @@ import pytest
 import torch
 
 from oracle import overlapnet_oracle as O
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = S.REFERENCE_MODEL_CFG

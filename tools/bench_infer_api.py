@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from overlapnet_amd import synthetic as S  # noqa: E402
+from tools import synthetic as S  # noqa: E402
 
 
 def engine_sweep(frames: int = 1101, C: int = 4):

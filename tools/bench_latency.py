@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd.engine import OvnEngine, decode_match
 
 C = 4

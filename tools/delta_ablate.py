@@ -5,7 +5,7 @@ Prints ms per 1024 pairs of the delta_c12 scope minus the prepare kernels (both 
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd.engine import OvnEngine
 torch.cuda.set_device(0)
 eng = OvnEngine(64, 900, 4)

@@ -4,7 +4,7 @@
 import os, sys, json
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd.engine import OvnEngine
 torch.cuda.set_device(0)
 eng = OvnEngine(64, 900, 4); eng.load_weights(S.make_test_weights(4, 0), S.REFERENCE_MODEL_CFG)

@@ -1,7 +1,7 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 from oracle import overlapnet_oracle as O
-from overlapnet_amd import synthetic as S
+from tools import synthetic as S
 from overlapnet_amd.engine import OvnEngine
 C=4
 w=S.make_test_weights(C,0)

@@ -1,4 +1,5 @@
-"""Seeded synthetic weights and inputs for parity tests, the smoke test and the benchmark.
+"""Seeded synthetic weights and inputs for parity tests, the smoke test and the benchmark (test / bench infrastructure: not part
+of the product package -- it reads the reference-generated fixtures under tests/golden/).
 
 The reference ships neither trained weights (`.gitignore:9`) nor KITTI sequences (`.gitignore:8`);
 what it does ship are two scans (`data/scans/00000{0,1}.bin`) whose reference-generated range /
@@ -12,7 +13,7 @@ from typing import Dict, Optional, Tuple
 
 import numpy as np
 
-from . import weights as W
+from overlapnet_amd import weights as W
 
 REPO_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN_PREPROCESS = os.path.join(REPO_ROOT, "tests", "golden", "kitti_preprocess.npz")
