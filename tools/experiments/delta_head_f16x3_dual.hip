@@ -669,6 +669,330 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
 #undef OVN_TILE_MFMA
 
 
+// ---- the same computation with the two waves of every SIMD in DIFFERENT phases ("dual") ----------------------------------
+// In the kernel above all 8 waves of the workgroup move through the phases of a pass together, so the matrix pipe idles while
+// they convert o1, run the latency-bound c_conv2 GEMM, reload L words or fill accumulators (~1/3 of a pass).  Here the waves
+// form two TEAMS of 4 (waves 0-3 and 4-7: one wave of either team on each SIMD).  A team owns all 360 rows (6 row tiles per
+// wave) of ONE column group per pass -- team 0 the even groups, team 1 the odd ones -- and team 1 runs LAG ticks behind team 0,
+// so that one team's epilogue ticks coincide with GEMM1 ticks of the other: whatever leaves the pipe idle in one wave of a
+// SIMD is covered by the MFMAs of its partner.  Time advances in TICKS separated by one workgroup barrier; per tick a team
+// executes one unit: a GEMM1 unit = one W1 chunk of 2 MFMA steps, or one of 4 epilogue units (o1 half 0 -> LDS, c_conv2 round
+// 0, o1 half 1, c_conv2 round 1 + stores + next pass's set-up).  A pass is 30 + 4 units.  Both teams consume the same W1
+// stream, team 1 exactly LAG ticks later, out of a ring of 6 chunk slots that all 16 waves... all 8 waves fill one tick ahead
+// of team 0 (W1 is staged once per workgroup, as above).  LDS: o1 half-K image of one group 49,920 B (the teams' epilogues
+// never overlap) + the packed R rows of both teams 15,360 B + ring 6 x 16,384 B = 163,584 B of the CU's 163,840.
+constexpr int DU_T = 6;                          // row tiles per wave
+constexpr int DU_CH = 2;                         // MFMA steps per W1 chunk (= per GEMM1 unit)
+constexpr int DU_NCH = 4 * S / DU_CH;            // 30 chunks per pass
+constexpr int DU_EPI = 4;                        // epilogue units per pass
+constexpr int DU_PERIOD = DU_NCH + DU_EPI;       // 34 ticks per pass and team
+constexpr int DU_LAG = 4;                        // team 1 runs this many ticks behind team 0
+constexpr int DU_RING = 6;                       // chunk slots: staged 1 tick ahead of team 0, read by team 1 LAG ticks after it
+constexpr int DU_CHUNK_BYTES = DU_CH * STEP_BYTES;   // 16,384
+constexpr int DU_IMG_STRIDE = KHALF + 8;         // 520 fp16 per o1 image row
+constexpr size_t DU_IMG_BYTES = 2 * (size_t)G * DU_IMG_STRIDE * 2;   // hi + lo: 49,920
+constexpr size_t DU_RS_BYTES = 2 * (size_t)S * FC * 4;               // both teams' packed R rows: 15,360
+constexpr size_t DU_LDS_BYTES = DU_IMG_BYTES + DU_RS_BYTES + (size_t)DU_RING * DU_CHUNK_BYTES;
+static_assert(DU_LDS_BYTES <= 163840, "must fit the CU's LDS");
+static_assert(DU_LAG >= DU_EPI && DU_RING >= DU_LAG + 2, "epilogues of the two teams must not overlap; ring covers lag + staging");
+
+template <int ABL = 0>
+__global__ __launch_bounds__(512) void delta_c12_f16x3_dual_kernel(const unsigned* __restrict__ pl, const float* __restrict__ tl,
+                                                                  const float* __restrict__ a2s, const float* __restrict__ feats_r,
+                                                                  const int32_t* __restrict__ ridx,
+                                                                  const _Float16* __restrict__ w1p,
+                                                                  const _Float16* __restrict__ w2p, const float* __restrict__ b2,
+                                                                  const f32x4* __restrict__ scales, float* __restrict__ o2,
+                                                                  unsigned* __restrict__ o2max, int nsplit) {
+  constexpr int T = DU_T;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* imgh = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* imgl = imgh + G * DU_IMG_STRIDE;
+  unsigned* rs_all = reinterpret_cast<unsigned*>(smem_raw + DU_IMG_BYTES);
+  unsigned char* ring = smem_raw + DU_IMG_BYTES + DU_RS_BYTES;
+
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int team = wave >> 2;          // 0: even column groups, 1: odd ones, LAG ticks behind
+  const int tw = wave & 3;             // wave inside the team: rows 96 tw .. 96 tw + 95, output columns 32 tw .. 32 tw + 31
+  const int ttid = tid & 255;          // thread inside the team
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+  unsigned* rs = rs_all + team * (S * FC);
+
+  const unsigned* L = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4 sc = scales[2 * pair];
+  const float sa = sc[0], inv_a1 = sc[1], s1 = sc[2], inv_2 = sc[3];
+  const float csa = scales[2 * pair + 1][0];
+  const float k1 = -2.0f * inv_a1 * s1;   // powers of two: exact
+
+  // passes of this workgroup: team-passes p0 .. p1-1 of the pair's 12 (column group 2 p + team)
+  const int p0 = part * (G / 2) / nsplit, p1 = (part + 1) * (G / 2) / nsplit;
+  const int nticks = (p1 - p0) * DU_PERIOD;      // local ticks of a team
+
+  // this lane's L words: rows 96 tw + 16 t + lrow (t = 0..5), channels 32 g + 8 slice .. + 7; one base, row tiles 2 KB-words apart
+  const unsigned* Lrow = L + (16 * T * tw + lrow) * FC + 32 * g;
+  const int lrow_last = FW - 1 - (16 * T * tw + lrow);   // tile t exists for this lane iff 16 t <= lrow_last
+#define DU_LOAD_L(SL)                                                                                    \
+  _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
+    if (16 * t <= lrow_last) {                                                                           \
+      la[t][0] = *reinterpret_cast<const u32x4*>(Lrow + 16 * t * FC + 8 * (SL));                         \
+      la[t][1] = *reinterpret_cast<const u32x4*>(Lrow + 16 * t * FC + 8 * (SL) + 4);                     \
+    } else {                                                                                             \
+      la[t][0] = (u32x4){0u, 0u, 0u, 0u};                                                                \
+      la[t][1] = (u32x4){0u, 0u, 0u, 0u};                                                                \
+    }                                                                                                    \
+  }
+  // team set-up of a pass: packed R rows of its column group -> LDS, accumulators = -(T + A2[jb]) (sa sw1) / 2
+  const f32x4* tsrc = reinterpret_cast<const f32x4*>(tl + (size_t)pair * TL_ELEMS + (size_t)tw * (T * 4 * 64 * 4) + lane * 4);
+  const float* a2p = a2s + (size_t)pair * A2_ELEMS + lrow;
+  f32x4 acc[T][4];
+#define DU_PASS_SETUP(JB)                                                                                \
+  {                                                                                                      \
+    for (int i4 = ttid; i4 < S * FC / 4; i4 += 256)                                                      \
+      *reinterpret_cast<u32x4*>(rs + 4 * i4) = pack4(*reinterpret_cast<const f32x4*>(R + (JB)*S * FC + 4 * i4), sa, csa); \
+    _Pragma("unroll") for (int t = 0; t < T; ++t)                                                        \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) acc[t][nt] = tsrc[(t * 4 + nt) * 64] + a2p[(JB)*O1 + 16 * nt]; \
+  }
+
+  // ---- prologue: W1 chunk 0 -> ring slot 0, first pass set-up of both teams ----
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  constexpr int PFN = DU_CHUNK_BYTES / (512 * 16);   // 2 pieces of 16 B per thread and chunk
+  f32x4 pf[PFN];
+#pragma unroll
+  for (int q = 0; q < PFN; ++q) *reinterpret_cast<f32x4*>(ring + (q * 512 + tid) * 16) = *reinterpret_cast<const f32x4*>(w1bytes + (q * 512 + tid) * 16);
+  if (p0 < p1) DU_PASS_SETUP(2 * p0 + team)
+  __syncthreads();
+
+  // A tick: all 8 waves fetch the W1 chunk team 0 consumes in the NEXT tick (if that is one of its GEMM1 ticks) at the top, run
+  // their team's unit, store the chunk into its ring slot, and meet at the barrier.  Both teams execute the same tick sequence
+  // (so the global tick count is known to each), team 1 shifted by LAG idle ticks at the start, team 0 by LAG at the end.
+  int tick = 0;
+  bool stage = false;
+  int sn = 0;
+#define DU_TICK_BEGIN                                                                                         \
+  {                                                                                                           \
+    const int lt0n = tick + 1;                                                                                \
+    const int ppn = lt0n / DU_PERIOD;                                                                         \
+    const int un = lt0n - ppn * DU_PERIOD;                                                                    \
+    stage = lt0n < nticks && un < DU_NCH;                                                                     \
+    sn = DU_NCH * ppn + un; /* index in the W1 stream */                                                      \
+    if (stage) {                                                                                              \
+      const unsigned char* src = w1bytes + (size_t)un * DU_CHUNK_BYTES;                                       \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q) pf[q] = *reinterpret_cast<const f32x4*>(src + (q * 512 + tid) * 16); \
+    }                                                                                                         \
+  }
+#define DU_TICK_END                                                                                           \
+  {                                                                                                           \
+    if (stage) {                                                                                              \
+      unsigned char* dst = ring + (size_t)(sn % DU_RING) * DU_CHUNK_BYTES;                                    \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q) *reinterpret_cast<f32x4*>(dst + (q * 512 + tid) * 16) = pf[q]; \
+    }                                                                                                         \
+    __syncthreads();                                                                                          \
+    ++tick;                                                                                                   \
+  }
+
+  if (team == 1)
+    for (int i = 0; i < DU_LAG; ++i) {
+      DU_TICK_BEGIN
+      DU_TICK_END
+    }
+
+#pragma unroll 1
+  for (int pp = 0; pp < p1 - p0; ++pp) {
+    const int jb = 2 * (p0 + pp) + team;
+    // ================= GEMM1: 30 units = W1 chunks of 2 MFMA steps; the L words live only inside this loop =================
+    {
+      u32x4 la[T][2];
+      DU_LOAD_L(0)
+#pragma unroll 1
+      for (int u = 0; u < DU_NCH; ++u) {
+        DU_TICK_BEGIN
+        const unsigned char* slot = ring + (size_t)((DU_NCH * pp + u) % DU_RING) * DU_CHUNK_BYTES;
+#pragma unroll
+        for (int h = 0; h < DU_CH; ++h) {
+          const int v = DU_CH * u + h;
+          const int sl = v / S;
+          const int dj = v - sl * S;
+          const unsigned char* wbuf = slot + h * STEP_BYTES;
+          const unsigned* rrow = rs + dj * FC + 32 * g + 8 * sl;
+          const u32x4 ra0 = *reinterpret_cast<const u32x4*>(rrow);
+          const u32x4 ra1 = *reinterpret_cast<const u32x4*>(rrow + 4);
+          // two sweeps over the 6 row tiles so that only ONE half of the weight fragments (16 registers) is live at a time: the wh
+          // terms (ah wh + al wh) first, then ah wl with ah formed again (the min/perm VALU is hidden behind the MFMAs; 256
+          // registers do not hold 96 accumulators + 48 L words + 32 weight-fragment registers + the rest without spilling L)
+          {
+            f16x8 bh[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bh[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              f16x8 ah, al;
+              make_a(la[t][0], la[t][1], ra0, ra1, ah, al);
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[t][nt], 0, 0, 0);
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[t][nt], 0, 0, 0);
+            }
+          }
+          {
+            f16x8 bl[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bl[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+              f16x8 ah, al;
+              make_a(la[t][0], la[t][1], ra0, ra1, ah, al);
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[t][nt], 0, 0, 0);
+            }
+          }
+          if (dj == S - 1 && sl < 3) DU_LOAD_L(sl + 1)   // next channel slice
+        }
+        DU_TICK_END
+      }
+    }
+    // ================= epilogue: 4 units =================
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // ---- unit 2h: o1 half h (di 8h .. 8h+7) -> LDS image, hi/lo fp16 in c_conv2's A layout ----
+      DU_TICK_BEGIN
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 16 * T * tw + 16 * t + 4 * g + r;
+          const int ib = i / S;
+          const int dh = i - ib * S - 8 * h;
+          if (i < FW && dh >= 0 && dh < 8) {
+            f16x4 h4, l4;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+              _Float16 hh, ll;
+              split_f16(acc[t][nt][r] * k1, hh, ll);
+              h4[nt] = hh;
+              l4[nt] = ll;
+            }
+            *reinterpret_cast<f16x4*>(imgh + ib * DU_IMG_STRIDE + dh * O1 + 4 * lrow) = h4;
+            *reinterpret_cast<f16x4*>(imgl + ib * DU_IMG_STRIDE + dh * O1 + 4 * lrow) = l4;
+          }
+        }
+      }
+      DU_TICK_END
+      // ---- unit 2h+1: c_conv2 round h on the image.  The round-0 partial sums wait in their final o2 locations (raw
+      //      accumulators) for round 1: keeping them in registers across two ticks would cost 16 registers of every GEMM1 unit.
+      //      Round 1 also applies bias + ReLU, stores, and sets up the team's next pass (GEMM1 is done with rs and acc). ----
+      DU_TICK_BEGIN
+      {
+        const int nks = h ? 14 : 16;
+        f32x4 acc2[2][2];   // [n-tile][m-tile]
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int ib0 = lrow;
+        const int ib1 = (16 + lrow > G - 1) ? G - 1 : 16 + lrow;
+        const _Float16* a0h = imgh + ib0 * DU_IMG_STRIDE + 8 * g;
+        const _Float16* a0l = imgl + ib0 * DU_IMG_STRIDE + 8 * g;
+        const _Float16* a1h = imgh + ib1 * DU_IMG_STRIDE + 8 * g;
+        const _Float16* a1l = imgl + ib1 * DU_IMG_STRIDE + 8 * g;
+        const _Float16* wk0 = w2p + ((size_t)(2 * tw) * 2) * 512 + lane * 8 + (size_t)(h ? 16 : 0) * (8 * 2 * 512);
+        f16x8 wq[3][2][2];   // [slot][n-tile][hi/lo]: two k-steps in flight beside the one being consumed
+#define DU_W2_LOAD(SLOT, KS)                                                                  \
+  {                                                                                           \
+    const _Float16* wk = wk0 + (size_t)(KS) * (8 * 2 * 512);                                   \
+    wq[SLOT][0][0] = *reinterpret_cast<const f16x8*>(wk);                                     \
+    wq[SLOT][0][1] = *reinterpret_cast<const f16x8*>(wk + 512);                               \
+    wq[SLOT][1][0] = *reinterpret_cast<const f16x8*>(wk + 1024);                              \
+    wq[SLOT][1][1] = *reinterpret_cast<const f16x8*>(wk + 1536);                              \
+  }
+#define DU_W2_STEP(SLOT, KS)                                                                  \
+  {                                                                                           \
+    const f16x8 f0h = *reinterpret_cast<const f16x8*>(a0h + 32 * (KS));                       \
+    const f16x8 f0l = *reinterpret_cast<const f16x8*>(a0l + 32 * (KS));                       \
+    const f16x8 f1h = *reinterpret_cast<const f16x8*>(a1h + 32 * (KS));                       \
+    const f16x8 f1l = *reinterpret_cast<const f16x8*>(a1l + 32 * (KS));                       \
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][0][0], acc2[0][0], 0, 0, 0); \
+    acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][0][0], acc2[0][1], 0, 0, 0); \
+    acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][1][0], acc2[1][0], 0, 0, 0); \
+    acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][1][0], acc2[1][1], 0, 0, 0); \
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0l, wq[SLOT][0][0], acc2[0][0], 0, 0, 0); \
+    acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1l, wq[SLOT][0][0], acc2[0][1], 0, 0, 0); \
+    acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0l, wq[SLOT][1][0], acc2[1][0], 0, 0, 0); \
+    acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1l, wq[SLOT][1][0], acc2[1][1], 0, 0, 0); \
+    acc2[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][0][1], acc2[0][0], 0, 0, 0); \
+    acc2[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][0][1], acc2[0][1], 0, 0, 0); \
+    acc2[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0h, wq[SLOT][1][1], acc2[1][0], 0, 0, 0); \
+    acc2[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1h, wq[SLOT][1][1], acc2[1][1], 0, 0, 0); \
+  }
+        DU_W2_LOAD(0, 0)
+        DU_W2_LOAD(1, 1)
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ks += 3) {   // nks = 16 or 14: the tail steps are guarded
+          if (ks + 2 < nks) DU_W2_LOAD(2, ks + 2)
+          DU_W2_STEP(0, ks)
+          if (ks + 3 < nks) DU_W2_LOAD(0, ks + 3)
+          if (ks + 1 < nks) DU_W2_STEP(1, ks + 1)
+          if (ks + 4 < nks) DU_W2_LOAD(1, ks + 4)
+          if (ks + 2 < nks) DU_W2_STEP(2, ks + 2)
+        }
+#undef DU_W2_LOAD
+#undef DU_W2_STEP
+        if (h == 0) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int ib2 = 16 * mt + 4 * g + r;
+                if (ib2 < G) o2[(((long long)pair * G + ib2) * G + jb) * O2 + 32 * tw + 16 * nt + lrow] = acc2[nt][mt][r];
+              }
+        } else {
+          float vmax = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            const int p = 32 * tw + 16 * nt + lrow;
+            const float bv = b2[p];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int ib2 = 16 * mt + 4 * g + r;
+                if (ib2 < G) {
+                  float* dst = o2 + (((long long)pair * G + ib2) * G + jb) * O2 + p;
+                  const float v = fmaxf(fmaf(acc2[nt][mt][r] + *dst, inv_2, bv), 0.0f);   // + this lane's own round-0 partial
+                  *dst = v;
+                  vmax = fmaxf(vmax, v);
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+          if (lane == 0) atomicMax(o2max + pair, __float_as_uint(vmax));
+          if (pp + 1 < p1 - p0) DU_PASS_SETUP(jb + 2)
+        }
+      }
+      DU_TICK_END
+    }
+  }
+
+  if (team == 0)
+    for (int i = 0; i < DU_LAG; ++i) {
+      DU_TICK_BEGIN
+      DU_TICK_END
+    }
+#undef DU_TICK_BEGIN
+#undef DU_TICK_END
+#undef DU_LOAD_L
+#undef DU_PASS_SETUP
+}
+
 }  // namespace
 
 size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
@@ -721,6 +1045,16 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
                        ctx->hs.w1_colsum, ctx->hs.b1_absmax, scales, o2max, pl, tl, a2s);
   }
   OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+  static const int use_dual = getenv("OVN_DELTA_DUAL") ? atoi(getenv("OVN_DELTA_DUAL")) : 1;
+  if (use_dual) {
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_dual_kernel<0>), DU_LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL((delta_c12_f16x3_dual_kernel<0>), dim3(n * nsplit), dim3(512), DU_LDS_BYTES, stream, pl, tl, a2s, feats_r, ridx,
+                       reinterpret_cast<const _Float16*>(ctx->w1p_h), reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->c2.bias,
+                       scales, o2, o2max, nsplit);
+    OVN_HIP_CHECK(hipGetLastError());
+    return OVN_OK;
+  }
 #define OVN_DELTA_LAUNCH(ABLV)                                                                                                  \
   hipLaunchKernelGGL((delta_c12_f16x3_kernel<3, 8, ABLV>), dim3(n * nsplit), dim3(512), LDS_BYTES, stream, pl, tl, a2s, feats_r, ridx, \
                      reinterpret_cast<const _Float16*>(ctx->w1p_h), reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->c2.bias,  \
