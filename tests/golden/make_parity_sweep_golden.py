@@ -6,7 +6,8 @@ container and committed (a few hundred KB); `tests/test_parity_sweep.py` rebuild
 on the GPU box, runs the HIP path on them and compares every pair.  The test also re-runs the oracle live on a few
 pairs and asserts they equal this file (guards against a drift of the input recipe).
 
-    python tests/golden/make_parity_sweep_golden.py [--pool 1024] [--sets glorot trained_like]
+    python tests/golden/make_parity_sweep_golden.py [--pool 1024] [--channels 4] [--sets glorot trained_like]
+    (committed: pool 1024 at C = 4, and pool 128 at C = 1 and C = 5 for the trained-like set: *_c1_p128.npz, *_c5_p128.npz)
 
 Stored per weight set: overlap, logit (fp64), yaw, the top-2 gap of the correlation vector (relative, for the near-tie
 rule of SURVEY.md section 8c), max |corr| per pair, and an fp64 checksum of the oracle's query feature volume.
@@ -65,7 +66,8 @@ def main():
         w = S.WEIGHT_SETS[name](args.channels)
         print("weight set %s" % name, flush=True)
         out = oracle_sweep(args.pool, args.channels, w, log=lambda m: print(m, flush=True))
-        path = os.path.join(ROOT, "tests", "golden", "parity_sweep_%s.npz" % name)
+        suffix = "" if (args.pool, args.channels) == (1024, 4) else "_c%d_p%d" % (args.channels, args.pool)
+        path = os.path.join(ROOT, "tests", "golden", "parity_sweep_%s%s.npz" % (name, suffix))
         np.savez_compressed(path, pool=np.array([args.pool]), channels=np.array([args.channels]), **out)
         print("wrote %s: logits [%.2f, %.2f]" % (path, out["logit"].min(), out["logit"].max()), flush=True)
 

@@ -22,22 +22,25 @@ from tools import synthetic as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = S.REFERENCE_MODEL_CFG
-POOL, C = 1024, 4
+# (weight set, channels, pool): the benchmark configuration with both weight sets, and a shorter sweep at the other two channel
+# counts the reference's configs produce (depth only; depth + normals + intensity) with the wide-range weights
+CASES = [("glorot", 4, 1024), ("trained_like", 4, 1024), ("trained_like", 1, 128), ("trained_like", 5, 128)]
 
 # (name, leg arithmetic, head arithmetic, correlation form); the first row is what bench.py and `Infer` run by default
 MODES = [("default", None, None, "spectral"),
          ("all_f32", "f32", "f32", "direct")]
 
 
-def _golden(name):
-    with np.load(os.path.join(ROOT, "tests", "golden", "parity_sweep_%s.npz" % name)) as z:
+def _golden(name, C, POOL):
+    suffix = "" if (POOL, C) == (1024, 4) else "_c%d_p%d" % (C, POOL)
+    with np.load(os.path.join(ROOT, "tests", "golden", "parity_sweep_%s%s.npz" % (name, suffix))) as z:
         return {k: z[k] for k in z.files}
 
 
-@pytest.mark.parametrize("wset", list(S.WEIGHT_SETS))
-def test_golden_file_equals_live_oracle_on_sample(wset):
+@pytest.mark.parametrize("wset,C,POOL", CASES)
+def test_golden_file_equals_live_oracle_on_sample(wset, C, POOL):
     """CPU: the committed oracle outputs are what the oracle gives today on inputs rebuilt from the seeds."""
-    g = _golden(wset)
+    g = _golden(wset, C, POOL)
     assert int(g["pool"][0]) == POOL and g["overlap"].shape == (POOL,)
     w = S.WEIGHT_SETS[wset](C)
     fx = S.load_fixture_images()
@@ -61,10 +64,10 @@ def _stats(d):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")
-@pytest.mark.parametrize("wset", list(S.WEIGHT_SETS))
-def test_sweep_1024_every_pair_against_oracle(wset):
+@pytest.mark.parametrize("wset,C,POOL", CASES)
+def test_sweep_every_pair_against_oracle(wset, C, POOL):
     from overlapnet_amd.engine import OvnEngine
-    g = _golden(wset)
+    g = _golden(wset, C, POOL)
     w = S.WEIGHT_SETS[wset](C)
     eng = OvnEngine(64, 900, C)
     eng.load_weights(w, CFG)
@@ -115,7 +118,7 @@ def test_sweep_1024_every_pair_against_oracle(wset):
     os.makedirs(out_dir, exist_ok=True)
     path = os.path.join(out_dir, "r2_parity_1024.json")
     allrep = json.load(open(path)) if os.path.isfile(path) else {}
-    allrep[wset] = report
+    allrep[wset if (C, POOL) == (4, 1024) else "%s_c%d_p%d" % (wset, C, POOL)] = report
     json.dump(allrep, open(path, "w"), indent=1)
     assert not failures, failures
     # the default arithmetic has the error of an fp32 evaluation: within 2x of the all-fp32 mode (+ 2e-6 of fp32 noise floor)
