@@ -65,7 +65,12 @@ def rocprof_traffic(kernel_prefix: str):
     PMC summary under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md;
     see tools/summarize_rocprof.py) -- null if no summary names it.  Counters cannot be read live in-process."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")), key=os.path.getmtime)
+    import re
+
+    def tag_key(path):   # r1 < r1b < ... < r1j < r2a < r2f: (round, letter suffix); file times do not survive a checkout
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        return (int(m.group(1)), m.group(2)) if m else (-1, "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_summary.json")), key=tag_key)
     for f in reversed(files):
         try:
             t = json.load(open(f)).get("hbm_traffic_per_launch", {})

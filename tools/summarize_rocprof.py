@@ -16,8 +16,15 @@ import sys
 
 
 def short(name):
+    """Kernel name without namespace / argument list; rocprofv3 leaves some template kernels mangled
+    (_ZN12_GLOBAL__N_1<len><name>I...E...): the <len> characters after the length prefix are the plain name."""
+    import re
+    m = re.match(r"_ZN\d+_GLOBAL__N_1(\d+)", name)
+    if m:
+        k = int(m.group(1))
+        return name[m.end():m.end() + k]
     n = name.replace("(anonymous namespace)::", "").replace("void ", "")
-    return n.split("(")[0] if not n.startswith("conv_mfma") else n.split("(")[0]
+    return n.split("(")[0]
 
 
 def main():
