@@ -167,8 +167,8 @@ int ovn_set_leg_precision(ovn_ctx* ctx, int mode);
  * Between begin and end every kernel group launched through this context is bracketed by an event
  * pair; ovn_profile_end waits for them and returns, per class, the summed milliseconds and the number
  * of bracketed launches.  Classes: 0 leg convolutions (one entry per layer launch), 1 correlation head,
- * 2 fused Delta kernel (DeltaLayer+c_conv1+c_conv2), 3 c_conv3, 4 dense+sigmoid, 5 projection, 6 spectrum (DFT),
- * 7 spectral correlation head. Arrays of 8. */
+ * 2 Delta kernel (DeltaLayer+c_conv1 contraction; fp32 mode: fused with c_conv2), 3 c_conv3, 4 dense+sigmoid, 5 projection,
+ * 6 spectrum (DFT), 7 spectral correlation head, 8 Delta prepare kernels, 9 c_conv2 GEMM of the f16x3 Delta path. Arrays of 10. */
 int ovn_profile_begin(ovn_ctx* ctx);
 int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind);
 

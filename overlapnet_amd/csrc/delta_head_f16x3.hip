@@ -103,6 +103,17 @@ __device__ __forceinline__ u32x4 pack4(const f32x4& v, float sa, float csa) {
   return w;
 }
 
+// (x0, x1), already scaled -> packed fp16 hi pair (rtz) and lo pair (rne of the exact remainder; `one` = 1.0f in a register keeps
+// the fma from being folded into a subtraction that needs two more conversions)
+__device__ __forceinline__ void split_pair(float x0, float x1, float one, unsigned& hi_pk, unsigned& lo_pk) {
+  const f16x2 h = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  f16x2 l;
+  l[0] = (_Float16)__builtin_fmaf(x0, one, -(float)h[0]);
+  l[1] = (_Float16)__builtin_fmaf(x1, one, -(float)h[1]);
+  hi_pk = __builtin_bit_cast(unsigned, h);
+  lo_pk = __builtin_bit_cast(unsigned, l);
+}
+
 // A fragments (hi, lo) of min(l, r) for one 16-row tile and one MFMA step: 8 packed words per lane each side.
 __device__ __forceinline__ void make_a(const u32x4& l0, const u32x4& l1, const u32x4& r0, const u32x4& r1, f16x8& ah, f16x8& al) {
   u32x4 h, q;
@@ -668,18 +679,543 @@ __global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned
 #undef OVN_SLICE
 #undef OVN_TILE_MFMA
 
+// =====================================================================================================================
+// SPLIT path: c_conv1 (the min-term contraction) and c_conv2 as two kernels.
+//
+// c_conv1 is LINEAR (generateNet.py:96-99, activation='linear'), so with |l - r| = l' + r' - 2 min(l', r') (l' = l + c, r' = r + c)
+//     o2pre[ib][jb][p] = b2[p] + TT[ib][p] + AA[jb][p] - 2 sum_{di,o} M[15 ib + di][jb][o] W2[di][o][p]
+//     M[i][jb][o]  = sum_{dj,c} min(l'[i][c], r'[15 jb + dj][c]) W1[dj][c][o]          <- delta_c1_f16x3_kernel (99.4 % of the work)
+//     TT[ib][p]    = sum_{di,o} (b1[o] + sum_c l'[15 ib + di][c] Ws[c][o]) W2[di][o][p]  <- per pair, prepare kernel
+//     AA[jb][p]    = sum_o (sum_{dj,c} r'[15 jb + dj][c] W1[dj][c][o]) W2s[o][p]        <- per pair, prepare kernel
+// The c_conv1 kernel then has NO epilogue phase: it stores -2 M (scaled) as fp32 and goes on with the next column groups, its
+// registers hold nothing but the 96 accumulators, one L slice and the operand fragments, and every operand stream (W1 window,
+// packed R rows, packed L slices) arrives by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, no
+// exposed global-load latency.  c_conv2 becomes a streaming GEMM over the (n 576) x 960 matrix of -2 M rows
+// (delta_c2_f16x3_kernel, HBM-bound: 2.2 MB per pair).  In the fused kernel above the epilogue + c_conv2 phase cost 0.93 ms of
+// 5.5 (its MFMAs: 0.25), the exposed L loads 0.43, the W1 register staging 0.35.
+constexpr int R_PASS_WORDS = 2 * S * FC;            // packed R rows of one pass (two column groups): 3840 words = 15,360 B
+constexpr int LST_WAVE_BYTES = 6 * 1024;            // one wave's L slice: 3 row tiles x 2 x 16 B per lane
+constexpr int TT_STRIDE = K2 + 4;                   // floats per row of the T image in LDS (bank spread for the fp32 MFMA A reads)
+constexpr int LIN_ELEMS = 2 * G * O2;               // per pair: TT + b2 [24][128], AA [24][128]
+constexpr size_t O1RAW_ELEMS = (size_t)G * FW * O1; // per pair: [jb][i][o'] = 552,960 floats
+constexpr size_t PREP_SPLIT_LDS = ((size_t)G * TT_STRIDE + G * O1 + 2 * NWAVE) * sizeof(float);
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+  // LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16 l (the base is wave-uniform: it goes through M0)
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// Per pair: value range -> shift and scales; both volumes packed ONCE into the word streams the c_conv1 kernel DMAs into LDS
+//   pl[pair][s(4)][i(360)][g(4)][8]       L words, channel slice major: lane (row, g) of slice s reads 32 contiguous bytes
+//   pr[pair][jb(24)][s(4)][dj(15)][g(4)][8] R words in the order of one pass's LDS image (two column groups = 15,360 B contiguous)
+// and the linear terms lin[pair] = {TT + b2 [24][128], AA [24][128]} (fp32 MFMA on the T image in LDS / plain FMAs).
+// scales[2 pair] = {sa, -2 s1r / (sa sw1), s1r, 1 / (s1r sw2)}; s1r = scale of -2 M, bounded by 2 span max_o sum |W1[., o]|.
+__global__ __launch_bounds__(512) void delta_prepare_split_kernel(
+    const float* __restrict__ feats_l, const int32_t* __restrict__ lidx, const float* __restrict__ feats_r,
+    const int32_t* __restrict__ ridx, const _Float16* __restrict__ wsp, const float* __restrict__ w1col,
+    const float* __restrict__ b1, const float* __restrict__ a2raw, const float* __restrict__ w2raw,
+    const float* __restrict__ w2sum, const float* __restrict__ b2, float sw1, float sw2, float sws, float w1_colsum,
+    f32x4* __restrict__ scales, unsigned* __restrict__ o2max, unsigned* __restrict__ pl, unsigned* __restrict__ pr,
+    float* __restrict__ lin) {
+  extern __shared__ __attribute__((aligned(16))) float psm[];
+  float* Tl = psm;                       // [24][TT_STRIDE]: T[15 ib + di][o] at ib * TT_STRIDE + di * 64 + o
+  float* A2l = psm + G * TT_STRIDE;      // [24][64]
+  float* red = A2l + G * O1;             // [2][NWAVE]
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const float* Lf = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
+  const float* Rf = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4* L4 = reinterpret_cast<const f32x4*>(Lf);
+  const f32x4* R4 = reinterpret_cast<const f32x4*>(Rf);
+  float mx = -3.0e38f, mn = 3.0e38f;
+  for (int i = tid; i < OVN_FEAT_ELEMS / 4; i += 512) {
+    const f32x4 a = L4[i], b = R4[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+    mn = fminf(mn, fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(b[0], b[1]), fminf(b[2], b[3]))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+  }
+  if (lane == 0) {
+    red[wave] = mx;
+    red[NWAVE + wave] = mn;
+  }
+  __syncthreads();
+  mx = red[0];
+  mn = red[NWAVE];
+#pragma unroll
+  for (int w = 1; w < NWAVE; ++w) {
+    mx = fmaxf(mx, red[w]);
+    mn = fminf(mn, red[NWAVE + w]);
+  }
+  const float c = (mn < 0.0f) ? -mn : 0.0f;       // shift that makes both volumes non-negative
+  const float span = mx + c;                       // largest shifted value
+  const float sa = ovn_pow2_scale_for(span);
+  const float s1r = ovn_pow2_scale_for(2.0f * span * w1_colsum);
+  const float csa = c * sa;
+  if (tid == 0) {
+    scales[2 * pair] = (f32x4){sa, -2.0f * s1r / (sa * sw1), s1r, 1.0f / (s1r * sw2)};
+    scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
+    o2max[pair] = 0u;
+  }
+  // A2[jb][o] of this pair (true units): sum of the K slices of delta_a2_kernel + c (column sums of W1)
+  {
+    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_KSPLIT * A2_ELEMS;
+    for (int i = tid; i < A2_ELEMS; i += 512) {
+      float v = src[i];
+#pragma unroll
+      for (int k = 1; k < A2_KSPLIT; ++k) v += src[(size_t)k * A2_ELEMS + i];
+      A2l[i] = v + c * w1col[i & (O1 - 1)];
+    }
+  }
+  // R words in pass order
+  {
+    unsigned* Pr = pr + (size_t)pair * OVN_FEAT_ELEMS;
+    for (int i4 = tid; i4 < OVN_FEAT_ELEMS / 4; i4 += 512) {
+      const int jrow = i4 >> 5, ch = (i4 & 31) * 4;
+      const int jb = jrow / S, dj = jrow - jb * S;
+      const int gm = ch >> 5, s = (ch & 31) >> 3, e = ch & 7;
+      *reinterpret_cast<u32x4*>(Pr + ((jb * 4 + s) * S + dj) * 32 + gm * 8 + e) = pack4(R4[i4], sa, csa);
+    }
+  }
+  // L: wave w, row tiles 3w .. 3w+2.  A lane owns row lrow of the tile and channels 32 ks + 8 g .. + 7 of each 32-channel MFMA
+  // step, i.e. main-kernel lane group ks of slice g.
+  unsigned* P = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const float inv_t = 1.0f / (sa * sws);
+#pragma unroll 1
+  for (int t = 0; t < 3; ++t) {
+    const int i = 48 * wave + 16 * t + lrow;
+    if (16 * (3 * wave + t) >= FW) break;   // wave-uniform: the 24th row tile does not exist
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    u32x4 w0[4], w1[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (i < FW) {
+        const float* src = Lf + (size_t)i * FC + 32 * ks + 8 * g;
+        w0[ks] = pack4(*reinterpret_cast<const f32x4*>(src), sa, csa);
+        w1[ks] = pack4(*reinterpret_cast<const f32x4*>(src + 4), sa, csa);
+        unsigned* dst = P + ((size_t)(g * FW + i) * 4 + ks) * 8;
+        *reinterpret_cast<u32x4*>(dst) = w0[ks];
+        *reinterpret_cast<u32x4*>(dst + 4) = w1[ks];
+      } else {
+        w0[ks] = w1[ks] = (u32x4){0u, 0u, 0u, 0u};
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 h, q;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        h[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x07060302u);
+        q[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x05040100u);
+        h[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x07060302u);
+        q[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x05040100u);
+      }
+      const f16x8 ah = __builtin_bit_cast(f16x8, h), al = __builtin_bit_cast(f16x8, q);
+      const _Float16* wk = wsp + (size_t)ks * (4 * 2 * 512) + lane * 8;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(wk + (nt * 2) * 512), bl = *reinterpret_cast<const f16x8*>(wk + (nt * 2 + 1) * 512);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[nt], 0, 0, 0);
+      }
+    }
+    // the words hold (L + c) sa, so acc / (sa sws) = (L + c) Ws already includes the shift term
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float add = b1[16 * nt + lrow];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 48 * wave + 16 * t + 4 * g + r;
+        if (row < FW) {
+          const int ib = row / S;
+          Tl[ib * TT_STRIDE + (row - ib * S) * O1 + 16 * nt + lrow] = fmaf(acc[nt][r], inv_t, add);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* lp = lin + (size_t)pair * LIN_ELEMS;
+  // TT = T[24 x 960] W2[960 x 128] on the fp32 matrix cores; wave = n-tile, both m-tiles, four independent chains
+  {
+    const float* a0 = Tl + lrow * TT_STRIDE + g;
+    const float* a1 = Tl + ((16 + lrow < G) ? 16 + lrow : G - 1) * TT_STRIDE + g;
+    const float* bcol = w2raw + (size_t)g * O2 + 16 * wave + lrow;
+    f32x4 acc[2][2] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
+#pragma unroll 4
+    for (int ks = 0; ks < K2 / 4; ks += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const float b = bcol[(size_t)4 * (ks + u) * O2];
+        acc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[4 * (ks + u)], b, acc[0][u], 0, 0, 0);
+        acc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[4 * (ks + u)], b, acc[1][u], 0, 0, 0);
+      }
+    }
+    const float bv = b2[16 * wave + lrow];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const f32x4 v = acc[mt][0] + acc[mt][1];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ib = 16 * mt + 4 * g + r;
+        if (ib < G) lp[ib * O2 + 16 * wave + lrow] = v[r] + bv;
+      }
+    }
+  }
+  // AA[jb][p] = sum_o A2[jb][o] W2s[o][p]
+  for (int idx = tid; idx < G * O2; idx += 512) {
+    const int jb = idx >> 7, p = idx & (O2 - 1);
+    float s = 0.f;
+#pragma unroll 8
+    for (int o = 0; o < O1; ++o) s = fmaf(A2l[jb * O1 + o], w2sum[o * O2 + p], s);
+    lp[G * O2 + idx] = s;
+  }
+}
+
+// W2s[o][p] = sum_di W2[di][o][p] (fp64 accumulation, rounded once)
+__global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restrict__ w2, float* __restrict__ w2sum) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx < O1 * O2) {
+    double s = 0.0;
+    for (int di = 0; di < S; ++di) s += (double)w2[(size_t)di * O1 * O2 + idx];
+    w2sum[idx] = (float)s;
+  }
+}
+
+// c_conv1's min-term contraction.  One workgroup of 8 waves = one pair (or 1/nsplit of its 12 passes); wave w owns rows
+// 48w .. 48w+47 of TWO column groups per pass (96 accumulator registers), K walked channel-slice-major as in the fused kernel.
+// LDS: W1 window 2 x SPC x 8 KB | packed R rows of the current and the next pass 2 x 15,360 B | one L slice per wave 8 x 6 KB.
+// All three are filled by LDS-DMA issued one chunk (W1), one slice (L) or one pass (R) ahead; the chunk barrier's vmcnt(0) finds them
+// landed (a chunk is SPC x 72 MFMAs per wave = 3.3 us at SPC = 3).  Output: o1raw[pair][jb][i][o'] = -2 M s1r, o' = 4 (o & 15) + (o >> 4)
+// (the K order of W2p), 16 bytes per lane and accumulator row.
+template <int SPC>
+__global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __restrict__ pl, const unsigned* __restrict__ pr,
+                                                             const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
+                                                             float* __restrict__ o1raw, int rot, int nsplit) {
+  constexpr int CHB = SPC * STEP_BYTES;          // window chunk
+  constexpr int CPS = S / SPC;                   // chunks per channel slice
+  constexpr int NCH = 4 * CPS;                   // chunks per walk of K
+  constexpr int PFN = CHB / (512 * 16);          // DMA instructions per lane per chunk
+  static_assert(S % SPC == 0 && CHB % (512 * 16) == 0 && CPS >= 3, "bad chunking");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* wst = smem_raw;
+  unsigned* rbuf = reinterpret_cast<unsigned*>(smem_raw + 2 * CHB);
+  unsigned char* lst = smem_raw + 2 * CHB + 2 * RS_BYTES;
+
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const unsigned* L = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const unsigned* Rw = pr + (size_t)pair * OVN_FEAT_ELEMS;
+  const float krow = scales[2 * pair][1];
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  unsigned char* lmine = lst + wave * LST_WAVE_BYTES;
+
+  // lane's L source of tile t (rows past the volume re-read row 359: their accumulators are never stored)
+  int lsrc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    int i = 48 * wave + 16 * t + lrow;
+    i = i < FW ? i : FW - 1;
+    lsrc[t] = (i * 4 + g) * 8;
+  }
+#define OVN_DMA_L(SL)                                                                            \
+  _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                \
+    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t], lmine + (2 * t) * 1024);                      \
+    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t] + 4, lmine + (2 * t + 1) * 1024);              \
+  }
+#define OVN_DMA_W(CH, BUF)                                                                       \
+  _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                \
+      glds16(w1bytes + (size_t)(CH) * CHB + (q * 512 + tid) * 16, wst + (BUF) * CHB + (q * 512 + wave * 64) * 16);
+#define OVN_DMA_R(PASS, BUF)                                                                     \
+  {                                                                                              \
+    const unsigned* rsrc = Rw + (size_t)(PASS) * R_PASS_WORDS;                                    \
+    glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);                            \
+    if (wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
+  }
+
+  const int s0 = rot ? ((pair >> 3) & 3) : 0;
+  const int p_begin = part * (G / 2) / nsplit, p_end = (part + 1) * (G / 2) / nsplit;
+  int cur = 0, rcur = 0;
+  int chunk = CPS * s0;
+  OVN_DMA_W(chunk, 0)
+  OVN_DMA_R(p_begin, 0)
+  OVN_DMA_L(s0)
+  __syncthreads();
+
+  for (int pass = p_begin; pass < p_end; ++pass) {
+    f32x4 acc[2][3][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned* rb = rbuf + rcur * R_PASS_WORDS + 8 * g;
+#pragma unroll 1
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int sl = (s0 + q4) & 3;
+      u32x4 la[3][2];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        la[t][0] = *reinterpret_cast<const u32x4*>(lmine + (2 * t) * 1024 + lane * 16);
+        la[t][1] = *reinterpret_cast<const u32x4*>(lmine + (2 * t + 1) * 1024 + lane * 16);
+      }
+      const unsigned* rsl = rb + sl * (S * 32);
+#pragma unroll 1
+      for (int c5 = 0; c5 < CPS; ++c5) {
+        const int nxt = (chunk + 1 == NCH) ? 0 : chunk + 1;
+        OVN_DMA_W(nxt, cur ^ 1)
+        if (c5 == 1) OVN_DMA_L((sl + 1) & 3)                       // this wave read its la registers a barrier ago
+        if (c5 == 2 && q4 == 0 && pass + 1 < p_end) OVN_DMA_R(pass + 1, rcur ^ 1)
+#pragma unroll
+        for (int h = 0; h < SPC; ++h) {
+          const unsigned char* wbuf = wst + cur * CHB + h * STEP_BYTES;
+          const unsigned* rrow = rsl + (c5 * SPC + h) * 32;
+          const u32x4 ra0 = *reinterpret_cast<const u32x4*>(rrow);
+          const u32x4 ra1 = *reinterpret_cast<const u32x4*>(rrow + 4);
+          const u32x4 rb0 = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32);
+          const u32x4 rb1 = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32 + 4);
+          f16x8 bh[4], bl[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            bh[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);
+            bl[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            f16x8 ah, al;
+            make_a(la[t][0], la[t][1], ra0, ra1, ah, al);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[0][t][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[0][t][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[0][t][nt], 0, 0, 0);
+            make_a(la[t][0], la[t][1], rb0, rb1, ah, al);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[nt], acc[1][t][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[nt], acc[1][t][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) acc[1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[nt], acc[1][t][nt], 0, 0, 0);
+          }
+        }
+        __syncthreads();   // vmcnt(0): the DMAs issued above have landed; every wave is done with window buffer `cur`
+        cur ^= 1;
+        chunk = nxt;
+      }
+    }
+    // -2 M s1r -> o1raw[pair][2 pass + j][i][4 lrow .. + 3]; the stores drain behind the next pass's first chunk
+    float* obase = o1raw + ((size_t)pair * G + 2 * pass) * (FW * O1) + 4 * lrow;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = 48 * wave + 16 * t + 4 * g + r;
+          if (i < FW) {
+            const f32x4 v = {acc[j][t][0][r] * krow, acc[j][t][1][r] * krow, acc[j][t][2][r] * krow, acc[j][t][3][r] * krow};
+            *reinterpret_cast<f32x4*>(obase + (size_t)j * (FW * O1) + i * O1) = v;
+          }
+        }
+    rcur ^= 1;
+  }
+#undef OVN_DMA_L
+#undef OVN_DMA_W
+#undef OVN_DMA_R
+}
+
+// c_conv2 on the stored -2 M rows: a (n 576) x 960 x 128 GEMM, HBM-bound (3840 B read per row, 0.2 ms of MFMA per 1024 pairs).
+// Workgroup = 192 consecutive rows of one pair (8 column groups jb x 24 ib), 4 waves x 48 rows x all 128 columns; the A rows are
+// read straight into registers two k-steps ahead (each element is used by one wave only) and split to fp16 hi/lo there, W2's
+// k-step slabs (16 KB, shared by the 4 waves) go through a double-buffered LDS window.  Epilogue: + TT[ib] + AA[jb] + b2, ReLU.
+__global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __restrict__ o1raw, const _Float16* __restrict__ w2p,
+                                                                const float* __restrict__ lin, const f32x4* __restrict__ scales,
+                                                                float* __restrict__ o2, unsigned* __restrict__ o2max, float one) {
+  __shared__ __attribute__((aligned(16))) unsigned char wb[2][16384];
+  constexpr int NKS = K2 / 32;   // 30
+  const int pair = blockIdx.x / 3, third = blockIdx.x - 3 * pair;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const float inv2 = scales[2 * pair][3];
+  const int row0 = third * 192 + 48 * wave;   // row within the pair: jb * 24 + ib
+  const float* abase = o1raw + ((size_t)pair * (G * G) + row0 + lrow) * K2 + 8 * g;
+  const unsigned char* w2bytes = reinterpret_cast<const unsigned char*>(w2p);
+
+  f32x4 araw[3][3][2];   // [k-step mod 3][m-tile][half]
+  f32x4 wr[4];
+#define OVN_LOAD_A(SLOT, KS)                                                                       \
+  _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) {                                               \
+    araw[SLOT][mt][0] = *reinterpret_cast<const f32x4*>(abase + (size_t)mt * 16 * K2 + 32 * (KS));      \
+    araw[SLOT][mt][1] = *reinterpret_cast<const f32x4*>(abase + (size_t)mt * 16 * K2 + 32 * (KS) + 4);  \
+  }
+#define OVN_LOAD_W(KS) \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) wr[q] = *reinterpret_cast<const f32x4*>(w2bytes + (size_t)(KS) * 16384 + (q * 256 + tid) * 16);
+#define OVN_STORE_W(BUF) \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&wb[BUF][(q * 256 + tid) * 16]) = wr[q];
+
+  f32x4 acc[3][8];
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  OVN_LOAD_W(0)
+  OVN_LOAD_A(0, 0)
+  OVN_LOAD_A(1, 1)
+  OVN_STORE_W(0)
+  __syncthreads();
+
+#define OVN_C2_STEP(SLOT, KS)                                                                                     \
+  {                                                                                                               \
+    if ((KS) + 1 < NKS) OVN_LOAD_W((KS) + 1)                                                                      \
+    if ((KS) + 2 < NKS) OVN_LOAD_A(((SLOT) + 2) % 3, (KS) + 2)                                                    \
+    f16x8 ah[3], al[3];                                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) {                                                            \
+      unsigned h0, h1, h2, h3, l0, l1, l2, l3;                                                                    \
+      split_pair(araw[SLOT][mt][0][0], araw[SLOT][mt][0][1], one, h0, l0);                                        \
+      split_pair(araw[SLOT][mt][0][2], araw[SLOT][mt][0][3], one, h1, l1);                                        \
+      split_pair(araw[SLOT][mt][1][0], araw[SLOT][mt][1][1], one, h2, l2);                                        \
+      split_pair(araw[SLOT][mt][1][2], araw[SLOT][mt][1][3], one, h3, l3);                                        \
+      ah[mt] = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});                                                \
+      al[mt] = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});                                                \
+    }                                                                                                             \
+    const unsigned char* wcur = &wb[(KS) & 1][lane * 16];                                                         \
+    _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) {                                                            \
+      const f16x8 bh = *reinterpret_cast<const f16x8*>(wcur + (nt * 2) * 1024);                                   \
+      const f16x8 bl = *reinterpret_cast<const f16x8*>(wcur + (nt * 2 + 1) * 1024);                               \
+      _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                            \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);                 \
+      _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                            \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);                 \
+      _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                            \
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);                 \
+    }                                                                                                             \
+    if ((KS) + 1 < NKS) OVN_STORE_W(((KS) + 1) & 1)                                                               \
+    __syncthreads();                                                                                              \
+  }
+#pragma unroll 1
+  for (int ks = 0; ks < NKS; ks += 3) {
+    OVN_C2_STEP(0, ks)
+    OVN_C2_STEP(1, ks + 1)
+    OVN_C2_STEP(2, ks + 2)
+  }
+#undef OVN_C2_STEP
+#undef OVN_LOAD_A
+#undef OVN_LOAD_W
+#undef OVN_STORE_W
+
+  const float* lp = lin + (size_t)pair * LIN_ELEMS;
+  float vmax = 0.f;
+#pragma unroll
+  for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = row0 + 16 * mt + 4 * g + r;
+      const int jb = row / G, ib = row - jb * G;
+      float* dst = o2 + (((size_t)pair * G + ib) * G + jb) * O2 + lrow;
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt) {
+        const int p = 16 * nt + lrow;
+        const float v = fmaxf(fmaf(acc[mt][nt][r], inv2, lp[ib * O2 + p] + lp[G * O2 + jb * O2 + p]), 0.0f);
+        dst[16 * nt] = v;
+        vmax = fmaxf(vmax, v);
+      }
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+  if (lane == 0) atomicMax(o2max + pair, __float_as_uint(vmax));
+}
 
 }  // namespace
 
-size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
+size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right, bool split) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  if (split)
+    return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + 2 * al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
+           al((size_t)n * LIN_ELEMS * sizeof(float)) + al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float)) +
+           al((size_t)n * O1RAW_ELEMS * sizeof(float));
   return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
          al((size_t)n * TL_ELEMS * sizeof(float)) + al((size_t)n * A2_ELEMS * sizeof(float)) +
          al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float));
 }
 
+static int pick_nsplit(int n) {
+  // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
+  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair)
+  double best = 1e30;
+  for (const int d : {1, 2, 3, 4, 6, 12}) {
+    const double cost = (double)(((long long)n * d + 255) / 256) / d;
+    if (cost < best) best = cost;
+  }
+  for (const int d : {1, 2, 3, 4, 6, 12})
+    if ((double)(((long long)n * d + 255) / 256) / d <= 1.05 * best) return d;
+  return 1;
+}
+
+// split path: a2 + prepare (scope delta_prep), c_conv1 contraction (scope delta_c12), c_conv2 GEMM (scope delta_c2)
+static int delta_split_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+                               int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
+  constexpr int SPC = 3;
+  constexpr size_t C1_LDS = 2 * (size_t)SPC * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPC>), C1_LDS);
+  if (rc) return rc;
+  rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel), PREP_SPLIT_LDS);
+  if (rc) return rc;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  char* p = static_cast<char*>(scratch);
+  f32x4* scales = reinterpret_cast<f32x4*>(p);
+  p += al((size_t)n * 8 * sizeof(float));
+  unsigned* o2max = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * sizeof(unsigned));
+  unsigned* pl = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned));
+  unsigned* pr = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned));
+  float* lin = reinterpret_cast<float*>(p);
+  p += al((size_t)n * LIN_ELEMS * sizeof(float));
+  float* a2raw = reinterpret_cast<float*>(p);
+  p += al((size_t)(ridx ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float));
+  float* o1raw = reinterpret_cast<float*>(p);
+  *o2max_out = o2max;
+  const int nsplit = pick_nsplit(n);
+  {
+    OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
+    hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
+    hipLaunchKernelGGL(delta_prepare_split_kernel, dim3(n), dim3(512), PREP_SPLIT_LDS, stream, feats_l, lidx, feats_r, ridx,
+                       reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1, a2raw, ctx->w2raw, ctx->w2sum, ctx->c2.bias,
+                       ctx->hs.sw1, ctx->hs.sw2, ctx->hs.sws, ctx->hs.w1_colsum, scales, o2max, pl, pr, lin);
+  }
+  {
+    OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+    hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPC>), dim3(n * nsplit), dim3(512), C1_LDS, stream, pl, pr,
+                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit);
+  }
+  {
+    OvnProfScope ps(ctx, OVN_K_DELTA_C2, stream);
+    hipLaunchKernelGGL(delta_c2_f16x3_kernel, dim3(n * 3), dim3(256), 0, stream, o1raw, reinterpret_cast<const _Float16*>(ctx->w2p_h),
+                       lin, scales, o2, o2max, 1.0f);
+  }
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
+  if (ctx->delta_split) return delta_split_forward(ctx, feats_l, lidx, feats_r, ridx, n, scratch, o2max_out, o2, stream);
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_kernel<3, 8>), LDS_BYTES);
   if (rc) return rc;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -696,23 +1232,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   p += al((size_t)n * A2_ELEMS * sizeof(float));
   float* a2raw = reinterpret_cast<float*>(p);
   *o2max_out = o2max;
-  // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
-  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair, W1 window and R rows set up once)
-  int nsplit = 1;
-  {
-    double best = 1e30;
-    for (const int d : {1, 2, 3, 4, 6, 12}) {
-      const double cost = (double)(((long long)n * d + 255) / 256) / d;
-      if (cost < best) best = cost;
-    }
-    for (const int d : {1, 2, 3, 4, 6, 12}) {
-      const double cost = (double)(((long long)n * d + 255) / 256) / d;
-      if (cost <= 1.05 * best) {
-        nsplit = d;
-        break;
-      }
-    }
-  }
+  const int nsplit = pick_nsplit(n);
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
@@ -774,6 +1294,10 @@ int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const floa
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1sum, (size_t)FC * O1 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1col, (size_t)O1 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc(&ctx->wsp_h, (size_t)FC * O1 * 2 * sizeof(_Float16)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->w2raw, (size_t)K2 * O2 * sizeof(float)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->w2sum, (size_t)O1 * O2 * sizeof(float)));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->w2raw, c2_kernel_dev, (size_t)K2 * O2 * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  hipLaunchKernelGGL(delta_w2sum_kernel, dim3((O1 * O2 + 255) / 256), dim3(256), 0, stream, c2_kernel_dev, ctx->w2sum);
   OVN_HIP_CHECK(hipMemcpyAsync(ctx->w1raw, c1_kernel_dev, (size_t)K1 * O1 * sizeof(float), hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(delta_w1sum_kernel, dim3((FC * O1 + 255) / 256), dim3(256), 0, stream, c1_kernel_dev, ctx->w1sum, ctx->w1col);
   {   // scale of the tap-summed kernel (up to 15x the largest single weight)

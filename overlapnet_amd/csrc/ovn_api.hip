@@ -72,6 +72,7 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
   c->in_h = in_h;
   c->in_w = in_w;
   c->in_c = in_c;
+  if (const char* e = getenv("OVN_DELTA_FUSED")) c->delta_split = (atoi(e) == 0);   // A/B switch for tools/; default: split path
   int rc = ovn_spectral_prepare(c, nullptr);
   if (rc) {
     ovn_conv_release(&c->dft);
@@ -102,6 +103,8 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->w1sum) (void)hipFree(ctx->w1sum);
   if (ctx->w1col) (void)hipFree(ctx->w1col);
   if (ctx->wsp_h) (void)hipFree(ctx->wsp_h);
+  if (ctx->w2raw) (void)hipFree(ctx->w2raw);
+  if (ctx->w2sum) (void)hipFree(ctx->w2sum);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->actmax) (void)hipFree(ctx->actmax);
   delete ctx;
@@ -155,8 +158,10 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
     if (ctx->w1sum) (void)hipFree(ctx->w1sum);
     if (ctx->w1col) (void)hipFree(ctx->w1col);
     if (ctx->wsp_h) (void)hipFree(ctx->wsp_h);
+    if (ctx->w2raw) (void)hipFree(ctx->w2raw);
+    if (ctx->w2sum) (void)hipFree(ctx->w2sum);
     ctx->w1p_h = ctx->w2p_h = ctx->wsp_h = nullptr;
-    ctx->w1raw = ctx->w1sum = ctx->w1col = nullptr;
+    ctx->w1raw = ctx->w1sum = ctx->w1col = ctx->w2raw = ctx->w2sum = nullptr;
     ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
     ctx->head_set = false;
   }
@@ -321,7 +326,7 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   const size_t o3_bytes = fused ? (((size_t)cmax * 3 * sizeof(float) + 255) & ~(size_t)255)
                                 : (((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255);
   // f16x3 mode: per-pair scales, packed left volumes and linear terms of the min-form Delta kernel (289 KB per pair)
-  const size_t sc_bytes = fused ? ovn_delta_f16x3_scratch_bytes((int)cmax, ridx != nullptr) : 0;
+  const size_t sc_bytes = fused ? ovn_delta_f16x3_scratch_bytes((int)cmax, ridx != nullptr, ctx->delta_split != 0) : 0;
   int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes + sc_bytes, stream);
   if (rc) return rc;
   float* o2 = reinterpret_cast<float*>(ctx->ws);

@@ -132,6 +132,9 @@ struct ovn_ctx {
   float* w1sum = nullptr;  // c_conv1 kernel summed over its 15 taps, [128][64]: B operand of the left-volume linear term
   float* w1col = nullptr;  // [64] column sums of the c_conv1 kernel (shift term)
   void* wsp_h = nullptr;   // w1sum as scaled hi/lo fp16 fragments
+  float* w2raw = nullptr;  // c_conv2 kernel as registered, [960][128], and summed over its 15 taps, [64][128]: B operands of the
+  float* w2sum = nullptr;  // linear terms pushed through c_conv2 (split Delta path)
+  int delta_split = 1;     // f16x3 head: c_conv1 contraction and c_conv2 as two kernels (1) or the fused kernel (0, OVN_DELTA_FUSED=1)
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
   unsigned* actmax = nullptr;   // [32] float bits of max |activation| per leg layer input of the running call (f16x3 scales)
@@ -160,7 +163,7 @@ struct ovn_ctx {
 
 // kernel classes reported by ovn_profile_end
 enum { OVN_K_LEG = 0, OVN_K_CORR = 1, OVN_K_DELTA = 2, OVN_K_C3 = 3, OVN_K_DENSE = 4, OVN_K_PROJ = 5, OVN_K_SPECTRUM = 6,
-       OVN_K_CORR_SPECTRAL = 7, OVN_K_DELTA_PREP = 8, OVN_K_COUNT = 9 };
+       OVN_K_CORR_SPECTRAL = 7, OVN_K_DELTA_PREP = 8, OVN_K_DELTA_C2 = 9, OVN_K_COUNT = 10 };
 
 struct OvnProfScope {
   ovn_ctx* ctx;
@@ -211,7 +214,7 @@ int ovn_dense_sigmoid_forward(const ovn_ctx* ctx, const float* o3, int n, float*
 // (input of ovn_c3_dense_forward).
 int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const float* c1_bias_dev, const float* c2_kernel_dev,
                             hipStream_t stream);
-size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right);
+size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right, bool split);
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream);
 

@@ -361,7 +361,7 @@ class OvnEngine:
         self.leg_precision = mode
 
     PROFILE_KINDS = ("leg_conv", "corr_head", "delta_c12", "c_conv3", "dense_sigmoid", "projection", "spectrum",
-                     "corr_spectral", "delta_prep")
+                     "corr_spectral", "delta_prep", "delta_c2")
 
     def profile_begin(self) -> None:
         _lib.check(self.lib.ovn_profile_begin(self._h), "ovn_profile_begin")
