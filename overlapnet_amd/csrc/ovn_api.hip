@@ -72,7 +72,6 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
   c->in_h = in_h;
   c->in_w = in_w;
   c->in_c = in_c;
-  if (const char* e = getenv("OVN_DELTA_FUSED")) c->delta_split = (atoi(e) == 0);   // A/B switch for tools/; default: split path
   int rc = ovn_spectral_prepare(c, nullptr);
   if (rc) {
     ovn_conv_release(&c->dft);
@@ -103,7 +102,6 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->w1sum) (void)hipFree(ctx->w1sum);
   if (ctx->w1col) (void)hipFree(ctx->w1col);
   if (ctx->wsp_h) (void)hipFree(ctx->wsp_h);
-  if (ctx->w2raw) (void)hipFree(ctx->w2raw);
   if (ctx->w2sum) (void)hipFree(ctx->w2sum);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->actmax) (void)hipFree(ctx->actmax);
@@ -158,10 +156,9 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
     if (ctx->w1sum) (void)hipFree(ctx->w1sum);
     if (ctx->w1col) (void)hipFree(ctx->w1col);
     if (ctx->wsp_h) (void)hipFree(ctx->wsp_h);
-    if (ctx->w2raw) (void)hipFree(ctx->w2raw);
-    if (ctx->w2sum) (void)hipFree(ctx->w2sum);
+      if (ctx->w2sum) (void)hipFree(ctx->w2sum);
     ctx->w1p_h = ctx->w2p_h = ctx->wsp_h = nullptr;
-    ctx->w1raw = ctx->w1sum = ctx->w1col = ctx->w2raw = ctx->w2sum = nullptr;
+    ctx->w1raw = ctx->w1sum = ctx->w1col = ctx->w2sum = nullptr;
     ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
     ctx->head_set = false;
   }
@@ -317,7 +314,7 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
                           bool with_corr, hipStream_t stream) {
   const size_t o2_elems = (size_t)OVN_G * OVN_G * OVN_C2_OUT;   // 24*24*128 per pair
   const size_t o3_elems = (size_t)OVN_DENSE_IN;                 // 22*22*256 per pair
-  const int64_t chunk = 2048;                                   // pairs per pass: 1.6 GB of scratch
+  const int64_t chunk = 2048;                                   // pairs per pass: 6.6 GB of scratch in f16x3 mode
   const int64_t cmax = n < chunk ? n : chunk;
   const size_t o2_bytes = ((size_t)cmax * o2_elems * sizeof(float) + 255) & ~(size_t)255;
   // second scratch region: o3 (n,22,22,256) in fp32 mode; in f16x3 mode c_conv3 and the Dense layer are one kernel and only
@@ -325,8 +322,8 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   const bool fused = (ctx->head_mode != 0);
   const size_t o3_bytes = fused ? (((size_t)cmax * 3 * sizeof(float) + 255) & ~(size_t)255)
                                 : (((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255);
-  // f16x3 mode: per-pair scales, packed left volumes and linear terms of the min-form Delta kernel (289 KB per pair)
-  const size_t sc_bytes = fused ? ovn_delta_f16x3_scratch_bytes((int)cmax, ridx != nullptr, ctx->delta_split != 0) : 0;
+  // f16x3 mode: per-pair scales, packed volumes, linear terms and the c_conv1 rows between the two Delta kernels (2.9 MB per pair)
+  const size_t sc_bytes = fused ? ovn_delta_f16x3_scratch_bytes((int)cmax, ridx != nullptr) : 0;
   int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes + sc_bytes, stream);
   if (rc) return rc;
   float* o2 = reinterpret_cast<float*>(ctx->ws);

@@ -132,9 +132,7 @@ struct ovn_ctx {
   float* w1sum = nullptr;  // c_conv1 kernel summed over its 15 taps, [128][64]: B operand of the left-volume linear term
   float* w1col = nullptr;  // [64] column sums of the c_conv1 kernel (shift term)
   void* wsp_h = nullptr;   // w1sum as scaled hi/lo fp16 fragments
-  float* w2raw = nullptr;  // c_conv2 kernel as registered, [960][128], and summed over its 15 taps, [64][128]: B operands of the
-  float* w2sum = nullptr;  // linear terms pushed through c_conv2 (split Delta path)
-  int delta_split = 1;     // f16x3 head: c_conv1 contraction and c_conv2 as two kernels (1) or the fused kernel (0, OVN_DELTA_FUSED=1)
+  float* w2sum = nullptr;  // c_conv2 kernel summed over its 15 taps, [64][128]: the right-volume linear term pushed through c_conv2
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
   unsigned* actmax = nullptr;   // [32] float bits of max |activation| per leg layer input of the running call (f16x3 scales)
@@ -209,12 +207,12 @@ int ovn_delta_c12_forward(const ovn_ctx* ctx, const float* feats_l, const int32_
 int ovn_dense_sigmoid_forward(const ovn_ctx* ctx, const float* o3, int n, float* overlap, float* logit,
                               hipStream_t stream);
 
-// delta_head_f16x3.hip.  `scratch` (ovn_delta_f16x3_scratch_bytes(n, ridx != NULL) bytes, caller-owned) holds the per-pair
-// scales, the packed left volumes and the linear terms; *o2max_out points at the per-pair maxima of the c_conv2 output inside it
-// (input of ovn_c3_dense_forward).
+// delta_head_f16x3.hip.  `scratch` (ovn_delta_f16x3_scratch_bytes(n, ridx != NULL) bytes, caller-owned: 2.9 MB per pair) holds the
+// per-pair scales, both packed volumes, the linear terms and the c_conv1 min-term rows between the two kernels; *o2max_out points
+// at the per-pair maxima of the c_conv2 output inside it (input of ovn_c3_dense_forward).
 int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const float* c1_bias_dev, const float* c2_kernel_dev,
                             hipStream_t stream);
-size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right, bool split);
+size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right);
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream);
 

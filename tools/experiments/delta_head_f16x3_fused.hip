@@ -1,4 +1,4 @@
-// Delta head: DeltaLayer + c_conv1 + c_conv2 on the fp16 matrix cores with a scaled 3-term split
+// Delta head: DeltaLayer + c_conv1 + c_conv2 fused, on the fp16 matrix cores with a scaled 3-term split
 // (v_mfma_f32_16x16x32_f16, fp32 accumulate) for gfx950.  Reference: generateNet.py:15-61 (DeltaLayer), :96-106.
 //
 // Arithmetic ("f16x3"): every fp32 operand x is scaled by a power of two s (exact) and written as hi + lo, both fp16:
@@ -9,34 +9,34 @@
 //
 // The DeltaLayer in MIN FORM.  c_conv1 needs sum_k |l - r| w.  Forming and splitting |l - r| costs 5-8 VALU instructions per
 // element pair next to the 12 MFMAs they feed, and the matrix pipe hides only part of that (tools/experiments/ubench3.hip,
-// ubench5.hip).  Instead, with l' = l + c, r' = r + c >= 0 (c = -min(0, smallest value of the pair)):
-//     |l - r| = l' + r' - 2 min(l', r')
-//   * min COMMUTES with the split: for x >= 0 the word P(x) = fp16_rtz(x) << 16 | fp16_rne(x - hi) orders like x, hence
-//     P(min(l', r')) = min_u32(P(l'), P(r')).  Both volumes are packed once per pair by the prepare kernel; the inner loop is
-//     ONE v_min_u32 per element plus two v_perm_b32 per element pair that separate the hi and lo halves: 4 full-rate VALU per
-//     pair (100 ns per 12 MFMAs in ubench5.hip; the 12 MFMAs alone take 94).
-//   * the l' and r' terms are LINEAR, and so is c_conv1 itself (activation='linear', generateNet.py:96-99), so they are
-//     pushed through c_conv2 and added to its output per pair:
-//       o2pre[ib][jb][p] = b2[p] + TT[ib][p] + AA[jb][p] - 2 sum_{di,o} M[15 ib + di][jb][o] W2[di][o][p]
-//       M[i][jb][o]  = sum_{dj,c} min(l'[i][c], r'[15 jb + dj][c]) W1[dj][c][o]          <- delta_c1_f16x3_kernel (99.4 % of the work)
-//       TT[ib][p]    = sum_{di,o} (b1[o] + sum_c l'[15 ib + di][c] Ws[c][o]) W2[di][o][p]  <- prepare kernel (Ws = W1 summed over its taps)
-//       AA[jb][p]    = sum_o (sum_{dj,c} r'[15 jb + dj][c] W1[dj][c][o]) W2s[o][p]        <- a2 + prepare kernels (W2s = W2 summed over its taps)
-//   Numerics: the three terms are ~1.5x larger than their sum, so the fp32 accumulation error is that of an fp32 evaluation
-//   times ~2-3 (1e-6 of the largest c_conv1 output; tests/test_parity_sweep.py compares every pair of the benchmark sweep with fp64).
-//
-// Three kernels per call (plus delta_a2_kernel for the right volumes):
-//   delta_prepare_split_kernel  per pair: value range -> shift and scales, both volumes packed into the word streams below, TT, AA
-//   delta_c1_f16x3_kernel       the min-term contraction; NO epilogue phase: it stores -2 M (scaled, fp32) and goes on with the
-//                               next column groups; registers hold the 96 accumulators, one L slice and the operand fragments, and
-//                               every operand stream (W1 window, packed R rows, packed L slices) arrives by LDS-DMA
-//                               (global_load_lds_dwordx4): no staging registers, no ds_write pass, no exposed global-load latency
-//   delta_c2_f16x3_kernel       c_conv2 as a streaming GEMM over the (n 576) x 960 matrix of -2 M rows (2.2 MB per pair through HBM)
-// The one-kernel predecessor (o1 image in LDS, c_conv2 as an epilogue phase of every pass: 5.56 ms per 1024 pairs against
-// 4.2 + 0.6 + 0.33 here; its epilogue phase cost 0.93 ms for 0.25 ms of MFMAs, exposed L loads 0.43, W1 register staging 0.35)
-// is kept in tools/experiments/delta_head_f16x3_fused.hip.
+// ubench5.hip: 12 MFMAs alone 94 ns, with the bf16 split 130 ns, with an fp16 split via v_cvt_pkrtz / v_fma_mix 122 ns --
+// the conversions issue at a fraction of the plain VALU rate).  Instead:
+//     |l - r| = l + r - 2 min(l, r)
+//   * the l and r terms are LINEAR: sum_k l w collapses to a 360 x 128 x 64 product per left volume (T, with the kernel
+//     summed over its 15 taps), sum_k r w to a 24 x 1920 x 64 product per right volume (A2) -- 0.6 % of the work, done once
+//     per pair (delta_prepare_kernel) / once per right volume (delta_a2_kernel) on the fp32 matrix cores;
+//   * min(l, r) COMMUTES with the split: for x >= 0 the word P(x) = fp16 hi(x) << 16 | fp16 lo(x) (hi truncated, so lo >= 0)
+//     orders like x, hence P(min(l, r)) = min_u32(P(l), P(r)).  Both volumes are packed once per pair (L by the prepare
+//     kernel, R rows when they are staged in LDS) and the inner loop is ONE v_min_u32 per element plus two v_perm_b32 per
+//     element pair that separate the hi and lo halves: 4 full-rate VALU per pair instead of 8 (100 ns per 12 MFMAs in
+//     ubench5.hip, the 12 MFMAs alone take 94).
+//   The accumulators start at -(T + A2)/2 (scaled), so the 1920-deep contraction ends at -(c_conv1 output)/2 directly.
+//   Inputs need not be non-negative: a pair is shifted by c = -min(0, smallest value) first (|l - r| does not change).
+//   Numerics: l + r - 2 min(l, r) is evaluated without the rounding of the fp32 subtraction the reference performs, but the
+//   three sums are ~1.5x larger than the result, so the fp32 accumulation error is that of an fp32 evaluation times ~2-3
+//   (1e-6 of the largest c_conv1 output; tests/test_parity_sweep.py compares every pair of the benchmark sweep with fp64).
 //
 // Scales: weights statically (max |W| -> 2^14), features per PAIR (max over both volumes -> 2^14, so a pair's result does
-// not depend on the other pairs of the call), -2 M by the bound 2 span max_o sum|W1[.,o]|, T by |b1|max + span max_o sum|W1[.,o]|.
+// not depend on the other pairs of the call), the c_conv1 output by the bound |b1|max + max|l - r| max_o sum|W1[.,o]|.
+//
+// Work decomposition of the main kernel: one workgroup (8 waves) = one pair; wave w owns rows 48w..48w+47 (3 MFMA row tiles)
+// of the 360 x 64 c_conv1 output of TWO column groups jb, jb+1 at a time: the K walk of c_conv1 is shared by the two groups,
+// so every W1 fragment read from LDS, every staged W1 chunk, every barrier and every L slice load serves 24 MFMAs per row
+// tile.  K = (c, dj) is walked channel-slice-major: an MFMA step covers 32 channels (lane group g = lane>>4 takes channels
+// 32g + 8s .. 32g + 8s + 7 for slice s = 0..3) of one R row dj, and the 15 rows dj of a slice are consecutive steps -- a lane
+// needs only 8 words of L per row tile at a time.  W1 (hi and lo, pre-permuted to this order) streams through a
+// double-buffered 2 x 24 KB LDS window shared by the 8 waves; o1 goes to LDS as hi/lo fp16 in GEMM2's [24][960] A layout;
+// GEMM2 (c_conv2) reads its weights straight from L2, software-pipelined.  Earlier schedules: tools/experiments/.
 #include <math.h>
 #include <stdlib.h>
 
@@ -56,9 +56,20 @@ constexpr int O1 = OVN_C1_OUT;        // 64
 constexpr int O2 = OVN_C2_OUT;        // 128
 constexpr int K1 = S * FC;            // 1920
 constexpr int K2 = S * O1;            // 960
-constexpr int STEP_BYTES = 8192;      // W1 fragments of one MFMA step: [nt(4)][hi/lo][lane(64)][8 fp16]
-constexpr size_t RS_BYTES = 2 * (size_t)S * FC * 4;   // packed R rows of two column groups (one pass): 15,360 B
+constexpr int KHALF = 8 * O1;         // c_conv2 K per round: 512 (di 0..7), then 448 (di 8..14)
+constexpr int IMG_STRIDE = KHALF + 8; // fp16 elements per o1 image row in LDS: 1040 B = 65 16-B slots (odd)
+constexpr int IMG_ROWS = 2 * G;       // both column groups of a pass: 48 rows = 3 exact m-tiles
+constexpr int STEPS_PER_CHUNK = 3;    // MFMA steps per W1 window chunk; 5 chunks = one 15-step channel slice
+constexpr int NCHUNK = 4 * S / STEPS_PER_CHUNK;   // 20 chunks per column group
+constexpr int STEP_BYTES = 8192;      // [nt(4)][hi/lo][lane(64)][8 fp16]
+constexpr int CHUNK_BYTES = STEPS_PER_CHUNK * STEP_BYTES;
+constexpr size_t IMG_BYTES = 2 * (size_t)IMG_ROWS * IMG_STRIDE * 2;   // hi + lo: 99,840 B
+constexpr size_t RS_BYTES = 2 * (size_t)S * FC * 4;                    // packed R rows of two column groups: 15,360 B
+// the R rows live in the TAIL of the image region: GEMM1 reads them, the epilogue overwrites them (GEMM1 is done by then)
+constexpr size_t LDS_BYTES = IMG_BYTES + 2 * CHUNK_BYTES;
+static_assert(RS_BYTES <= IMG_BYTES, "the R rows alias the image tail");
 constexpr int NWAVE = 8;
+constexpr int TL_ELEMS = NWAVE * 3 * 4 * 64 * 4;   // floats of T per pair in accumulator order [wave][t][nt][lane][r]
 constexpr int A2_ELEMS = G * O1;                   // floats of A2 per right volume [jb][o]
 constexpr int A2_KSPLIT = 8;                       // K slices (workgroups) per right volume in delta_a2_kernel
 
@@ -258,6 +269,430 @@ __global__ void delta_prep_ws_f16_kernel(const float* __restrict__ w1sum, _Float
   }
 }
 
+// Per pair: value range of both volumes -> shift c and the power-of-two scales; then ONE pass over L in MFMA A-fragment order:
+// pack to P words (the main kernel's operand), and T = b1 + (L + c) Ws from those very words on the fp16 matrix cores (3-term
+// split against the scaled hi/lo fragments of Ws), stored pre-scaled by -(sa sw1)/2 in the main kernel's accumulator order;
+// A2 likewise (sum of delta_a2_kernel's K slices).
+// scales[2 pair] = {sa, 1/(sa sw1), s1, 1/(s1 sw2)}, scales[2 pair + 1] = {c sa, c, span, 0}.  o2max[pair] = 0.
+__global__ __launch_bounds__(512) void delta_prepare_kernel(const float* __restrict__ feats_l, const int32_t* __restrict__ lidx,
+                                                            const float* __restrict__ feats_r, const int32_t* __restrict__ ridx,
+                                                            const _Float16* __restrict__ wsp, const float* __restrict__ w1col,
+                                                            const float* __restrict__ b1, const float* __restrict__ a2raw,
+                                                            float sw1, float sw2, float sws, float w1_colsum, float b1_absmax,
+                                                            f32x4* __restrict__ scales, unsigned* __restrict__ o2max,
+                                                            unsigned* __restrict__ pl, float* __restrict__ tl, float* __restrict__ a2s) {
+  __shared__ float red[2][NWAVE];
+  const int pair = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const float* Lf = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
+  const float* Rf = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4* L4 = reinterpret_cast<const f32x4*>(Lf);
+  const f32x4* R4 = reinterpret_cast<const f32x4*>(Rf);
+  float mx = -3.0e38f, mn = 3.0e38f;
+  for (int i = tid; i < OVN_FEAT_ELEMS / 4; i += 512) {
+    const f32x4 a = L4[i], b = R4[i];
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
+    mn = fminf(mn, fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(b[0], b[1]), fminf(b[2], b[3]))));
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+  }
+  if (lane == 0) {
+    red[0][wave] = mx;
+    red[1][wave] = mn;
+  }
+  __syncthreads();
+  mx = red[0][0];
+  mn = red[1][0];
+#pragma unroll
+  for (int w = 1; w < NWAVE; ++w) {
+    mx = fmaxf(mx, red[0][w]);
+    mn = fminf(mn, red[1][w]);
+  }
+  const float c = (mn < 0.0f) ? -mn : 0.0f;       // shift that makes both volumes non-negative
+  const float span = mx + c;                       // largest shifted value = bound of |l - r|
+  const float sa = ovn_pow2_scale_for(span);
+  const float s1 = ovn_pow2_scale_for(b1_absmax + span * w1_colsum);
+  const float csa = c * sa;
+  const float kneg = -0.5f * sa * sw1;
+  if (tid == 0) {
+    scales[2 * pair] = (f32x4){sa, 1.0f / (sa * sw1), s1, 1.0f / (s1 * sw2)};
+    scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
+    o2max[pair] = 0u;   // running max of the pair's c_conv2 output (float bits; values are >= 0), filled by the main kernel
+  }
+  // A2 of this pair: (sum of the K slices of A2raw + c wcol) kneg
+  {
+    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_KSPLIT * A2_ELEMS;
+    float* dst = a2s + (size_t)pair * A2_ELEMS;
+    for (int i = tid; i < A2_ELEMS; i += 512) {
+      float v = src[i];
+#pragma unroll
+      for (int k = 1; k < A2_KSPLIT; ++k) v += src[(size_t)k * A2_ELEMS + i];
+      dst[i] = (v + c * w1col[i & (O1 - 1)]) * kneg;
+    }
+  }
+  // L: wave w, row tiles 3w .. 3w+2.  A lane owns row lrow of the tile and channels 32 ks + 8 g .. + 7 of each 32-channel step.
+  unsigned* P = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  float* tdst = tl + (size_t)pair * TL_ELEMS + (size_t)wave * (3 * 4 * 64 * 4) + lane * 4;
+  const float inv_t = 1.0f / (sa * sws);
+#pragma unroll 1
+  for (int t = 0; t < 3; ++t) {
+    const int i = 48 * wave + 16 * t + lrow;
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (16 * (3 * wave + t) < FW) {   // wave-uniform: the 24th row tile does not exist
+      u32x4 w0[4], w1[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (i < FW) {
+          const float* src = Lf + (size_t)i * FC + 32 * ks + 8 * g;
+          w0[ks] = pack4(*reinterpret_cast<const f32x4*>(src), sa, csa);
+          w1[ks] = pack4(*reinterpret_cast<const f32x4*>(src + 4), sa, csa);
+          *reinterpret_cast<u32x4*>(P + (size_t)i * FC + 32 * ks + 8 * g) = w0[ks];
+          *reinterpret_cast<u32x4*>(P + (size_t)i * FC + 32 * ks + 8 * g + 4) = w1[ks];
+        } else {
+          w0[ks] = w1[ks] = (u32x4){0u, 0u, 0u, 0u};
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        u32x4 h, q;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          h[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x07060302u);
+          q[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x05040100u);
+          h[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x07060302u);
+          q[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x05040100u);
+        }
+        const f16x8 ah = __builtin_bit_cast(f16x8, h), al = __builtin_bit_cast(f16x8, q);
+        const _Float16* wk = wsp + (size_t)ks * (4 * 2 * 512) + lane * 8;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f16x8 bh = *reinterpret_cast<const f16x8*>(wk + (nt * 2) * 512), bl = *reinterpret_cast<const f16x8*>(wk + (nt * 2 + 1) * 512);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    // the words hold (L + c) sa, so acc / (sa sws) = (L + c) Ws already includes the shift term
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float add = b1[16 * nt + lrow];
+      f32x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (48 * wave + 16 * t + 4 * g + r < FW) ? fmaf(acc[nt][r], inv_t, add) * kneg : 0.0f;
+      *reinterpret_cast<f32x4*>(tdst + (size_t)(t * 4 + nt) * 256) = v;
+    }
+  }
+}
+
+// ABL: timing-only ablations for tools/delta_ablate.py (wrong results; compiled only with -DOVN_ABLATE, product = 0):
+//   1 no epilogue / GEMM2, 2 no L slice reloads, 4 no W1 staging, 8 no chunk barrier, 16 no min/perm VALU, 32 no GEMM1 MFMAs,
+//   64 no pass prologue (R staging, T/A2 loads), 128 L slice loads issued a chunk ahead instead of at the slice boundary (A/B in one run: 5.55-5.74 vs 5.35-5.42 ms)
+template <int T, int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW) void delta_c12_f16x3_kernel(const unsigned* __restrict__ pl,
+                                                                  const float* __restrict__ tl, const float* __restrict__ a2s,
+                                                                  const float* __restrict__ feats_r,
+                                                                  const int32_t* __restrict__ ridx,
+                                                                  const _Float16* __restrict__ w1p,
+                                                                  const _Float16* __restrict__ w2p,
+                                                                  const float* __restrict__ b2,
+                                                                  const f32x4* __restrict__ scales, float* __restrict__ o2,
+                                                                  unsigned* __restrict__ o2max, int rot, int nsplit) {
+  static_assert(T == 3 && NW == NWAVE, "T is stored for 8 waves x 3 row tiles");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  _Float16* imgh = reinterpret_cast<_Float16*>(smem_raw);
+  _Float16* imgl = imgh + IMG_ROWS * IMG_STRIDE;
+  unsigned* rs = reinterpret_cast<unsigned*>(smem_raw + IMG_BYTES - RS_BYTES);   // packed R rows (alias of the image tail)
+  unsigned char* wst = smem_raw + IMG_BYTES;                                      // 2 x 24 KB window
+
+  // nsplit > 1 (small sweeps): the 12 column-group passes of a pair are spread over nsplit workgroups, so that a handful of
+  // pairs still fills the chip (a pair's latency drops from 1.4 ms to 1.4 / nsplit ms; no work is duplicated)
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const unsigned* L = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const float* R = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const f32x4 sc = scales[2 * pair];
+  const float sa = sc[0], inv_a1 = sc[1], s1 = sc[2], inv_2 = sc[3];
+  const float csa = scales[2 * pair + 1][0];
+
+  // this lane's slice of L for channel slice s: rows 48*wave + 16*t + lrow, channels 32g + 8s .. +7
+  constexpr int NT_ = 64 * NW;                       // threads
+  constexpr int PFN = CHUNK_BYTES / (NT_ * 16);      // 16-byte window pieces per thread per chunk
+  static_assert(CHUNK_BYTES % (NT_ * 16) == 0 && T * NW * 16 >= FW, "bad tiling");
+  int lrow_off[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int i = 16 * T * wave + 16 * t + lrow;
+    lrow_off[t] = (i < FW) ? i * FC + 32 * g : -1;
+  }
+  u32x4 la[T][2], lb[T][2];   // L words of the current / the next channel slice (ping-pong)
+#define OVN_LOAD_L(DST, SL)                                                                              \
+  _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                        \
+    if ((ABL & 2) && (SL) != s0) {                                                                       \
+    } else if (lrow_off[t] >= 0) {                                                                              \
+      DST[t][0] = (ABL & 256) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL)))      \
+                              : *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL));                           \
+      DST[t][1] = (ABL & 256) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4))  \
+                              : *reinterpret_cast<const u32x4*>(L + lrow_off[t] + 8 * (SL) + 4);                       \
+    } else {                                                                                             \
+      DST[t][0] = (u32x4){0u, 0u, 0u, 0u};                                                               \
+      DST[t][1] = (u32x4){0u, 0u, 0u, 0u};                                                               \
+    }                                                                                                    \
+  }
+  // Workgroups walk the channel slices (and with them the W1 stream) in rotated order: the 32 CUs of an XCD then
+  // touch every W1 line several times per column-group period instead of in one burst, which keeps the 1 MB of
+  // weights resident in the 4 MB L2 under the private L / o2 streams (LRU thrash otherwise: 18.7 GB/launch of misses).
+  const int s0 = rot ? ((pair >> 3) & 3) : 0;
+  const int s1i = (s0 + 1) & 3, s2i = (s0 + 2) & 3, s3i = (s0 + 3) & 3;
+  OVN_LOAD_L(la, s0)
+
+  // W1 chunk 0 -> LDS buffer 0 (every column group walks the same 20 chunks, so the window just wraps)
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  f32x4 pf[PFN];
+#pragma unroll
+  for (int q = 0; q < PFN; ++q) {
+    pf[q] = *reinterpret_cast<const f32x4*>(w1bytes + (size_t)(5 * s0) * CHUNK_BYTES + (q * NT_ + tid) * 16);
+    *reinterpret_cast<f32x4*>(wst + (q * NT_ + tid) * 16) = pf[q];
+  }
+  int cur = 0;
+  int chunk = 5 * s0;  // running chunk index 0..19 (cyclic), 5 chunks per slice
+
+  // 12 MFMAs of one row tile; term-major so consecutive MFMAs never chain on one accumulator
+#define OVN_TILE_MFMA(J, T, AH, AL)                                                                       \
+  if (ABL & 32) {                                                                                          \
+    acc[J][T][0] += __builtin_bit_cast(f32x4, AH);                                                         \
+    acc[J][T][1] += __builtin_bit_cast(f32x4, AL);                                                         \
+  } else {                                                                                                 \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, bh[nt], acc[J][T][nt], 0, 0, 0);         \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AL, bh[nt], acc[J][T][nt], 0, 0, 0);         \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+      acc[J][T][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AH, bl[nt], acc[J][T][nt], 0, 0, 0);         \
+  }
+  // One channel slice SL (15 MFMA steps = 5 window chunks) with the L slice held in LX.
+#define OVN_SLICE(LX, SL, LNEXT, SLNEXT)                                                                          \
+  {                                                                                                               \
+    for (int c5 = 0; c5 < S / STEPS_PER_CHUNK; ++c5) {                                                            \
+      if ((ABL & 128) && c5 == S / STEPS_PER_CHUNK - 1) OVN_LOAD_L(LNEXT, SLNEXT) /* ablation: a chunk ahead */          \
+      const int nxt = (chunk + 1 == NCHUNK) ? 0 : chunk + 1;                                                      \
+      const unsigned char* src = w1bytes + (size_t)nxt * CHUNK_BYTES;                                             \
+      if (!(ABL & 4)) {                                                                                           \
+      _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                             \
+          pf[q] = *reinterpret_cast<const f32x4*>(src + (q * NT_ + tid) * 16);                                    \
+      }                                                                                                           \
+      _Pragma("unroll") for (int h = 0; h < STEPS_PER_CHUNK; ++h) {                                               \
+        const int dj = c5 * STEPS_PER_CHUNK + h;                                                                  \
+        const unsigned char* wbuf = wst + cur * CHUNK_BYTES + h * STEP_BYTES;                                     \
+        const unsigned* rrow = rs + dj * FC + 32 * g + 8 * (SL);                                                  \
+        const u32x4 ra0 = *reinterpret_cast<const u32x4*>(rrow);                                                  \
+        const u32x4 ra1 = *reinterpret_cast<const u32x4*>(rrow + 4);                                              \
+        const u32x4 rb0 = *reinterpret_cast<const u32x4*>(rrow + S * FC);                                         \
+        const u32x4 rb1 = *reinterpret_cast<const u32x4*>(rrow + S * FC + 4);                                     \
+        f16x8 bh[4], bl[4];                                                                                       \
+        _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                        \
+          bh[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);                       \
+          bl[nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);                       \
+        }                                                                                                         \
+        _Pragma("unroll") for (int t = 0; t < T; ++t) {                                                           \
+          f16x8 ah, al;                                                                                           \
+          if (ABL & 16) {                                                                                         \
+            ah = __builtin_bit_cast(f16x8, LX[t][0] ^ ra0);                                                       \
+            al = __builtin_bit_cast(f16x8, LX[t][1] ^ ra1);                                                       \
+          } else make_a(LX[t][0], LX[t][1], ra0, ra1, ah, al);                                                    \
+          OVN_TILE_MFMA(0, t, ah, al)                                                                             \
+          if (ABL & 16) {                                                                                         \
+            ah = __builtin_bit_cast(f16x8, LX[t][0] ^ rb0);                                                       \
+            al = __builtin_bit_cast(f16x8, LX[t][1] ^ rb1);                                                       \
+          } else make_a(LX[t][0], LX[t][1], rb0, rb1, ah, al);                                                    \
+          OVN_TILE_MFMA(1, t, ah, al)                                                                             \
+        }                                                                                                         \
+      }                                                                                                           \
+      if (!(ABL & 4)) {                                                                                           \
+        unsigned char* dstw = wst + (cur ^ 1) * CHUNK_BYTES;                                                      \
+        _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                           \
+            *reinterpret_cast<f32x4*>(dstw + (q * NT_ + tid) * 16) = pf[q];                                       \
+      }                                                                                                           \
+      if (!(ABL & 8)) __syncthreads();                                                                            \
+      cur ^= 1;                                                                                                   \
+      chunk = nxt;                                                                                                \
+    }                                                                                                             \
+    if (!(ABL & 128)) OVN_LOAD_L(LNEXT, SLNEXT) /* exposed; prefetching it a chunk ahead (128) slows GEMM2 more */ \
+  }
+
+  const f32x4* tsrc = reinterpret_cast<const f32x4*>(tl + (size_t)pair * TL_ELEMS + (size_t)wave * (T * 4 * 64 * 4) + lane * 4);
+  const float* a2p = a2s + (size_t)pair * A2_ELEMS + lrow;
+
+  for (int jb2 = part * (G / 2) / nsplit; jb2 < (part + 1) * (G / 2) / nsplit; ++jb2) {
+    __syncthreads();  // previous pass's GEMM2 is done with the o1 image (whose tail the R rows alias); W window write above is visible
+    if (!(ABL & 64))
+    for (int i4 = tid; i4 < 2 * S * FC / 4; i4 += NT_)
+      *reinterpret_cast<u32x4*>(rs + 4 * i4) = pack4(*reinterpret_cast<const f32x4*>(R + jb2 * 2 * S * FC + 4 * i4), sa, csa);
+
+    // accumulators start at -(T[i][o] + A2[jb][o]) (sa sw1) / 2: the contraction then ends at -(c_conv1 output)(sa sw1)/2
+    f32x4 acc[2][T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        if (ABL & 64) {
+          acc[0][t][nt] = acc[1][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          continue;
+        }
+        const f32x4 tv = (ABL & 256) ? __builtin_nontemporal_load(tsrc + (t * 4 + nt) * 64) : tsrc[(t * 4 + nt) * 64];
+        acc[0][t][nt] = tv + a2p[(2 * jb2) * O1 + 16 * nt];
+        acc[1][t][nt] = tv + a2p[(2 * jb2 + 1) * O1 + 16 * nt];
+      }
+    __syncthreads();
+
+    OVN_SLICE(la, s0, lb, s1i)
+    OVN_SLICE(lb, s1i, la, s2i)
+    OVN_SLICE(la, s2i, lb, s3i)
+    OVN_SLICE(lb, s3i, la, s0)
+
+    if (ABL & 1) {   // keep the accumulators alive
+      f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) sacc += acc[j][t][nt];
+      if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 123.456f) o2[tid] = sacc[0];
+      continue;
+    }
+    // ---- epilogue + c_conv2 for BOTH column groups at once, half of c_conv2's K at a time ----
+    // o1 = -2 acc / (sa sw1), scaled by s1, goes to LDS as hi/lo fp16 in GEMM2's A layout: image row m = 24 j + ib (48 rows = 3
+    // exact m-tiles), K order k' = dh*64 + 4*lrow + nt within the half (dh = di for di < 8, di - 8 above; see the W2 prep
+    // kernel).  48 rows x (512 + 8) x hi/lo = 99,840 B: the o1 region plus the R-word rows behind it, which GEMM1 is done with.
+    // One W2 fragment fetch and one barrier sequence then serve both groups, and no MFMA row is padding (2 x 2 m-tiles of 16 for
+    // 2 x 24 rows were 25 % padding; W2 was fetched once per group).
+    {
+      const float k1 = -2.0f * inv_a1 * s1;   // powers of two: exact
+      f32x4 acc2t[3][3];                       // [m-tile][split term]: nine independent MFMA chains
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int t3 = 0; t3 < 3; ++t3) acc2t[mt][t3] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const _Float16* wcol = w2p + ((size_t)wave * 2) * 512 + lane * 8;   // this wave's n-tile: [ks][nt(8)][hl][lane][8]
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1) __syncthreads();   // round 0 of GEMM2 is done reading the image
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int t = 0; t < T; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int i = 16 * T * wave + 16 * t + 4 * g + r;
+              const int ib = i / S;
+              const int dh = i - ib * S - 8 * h;
+              if (i < FW && dh >= 0 && dh < 8) {
+                f16x4 h4, l4;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                  _Float16 hh, ll;
+                  split_f16(acc[j][t][nt][r] * k1, hh, ll);
+                  h4[nt] = hh;
+                  l4[nt] = ll;
+                }
+                *reinterpret_cast<f16x4*>(imgh + (G * j + ib) * IMG_STRIDE + dh * O1 + 4 * lrow) = h4;
+                *reinterpret_cast<f16x4*>(imgl + (G * j + ib) * IMG_STRIDE + dh * O1 + 4 * lrow) = l4;
+              }
+            }
+          }
+        __syncthreads();
+        // GEMM2 round h: (48 x K_h) x (K_h x 128), K_0 = 512 (16 k-steps), K_1 = 448 (14); W2 fragments straight from L2, one
+        // k-step ahead in flight while the current one feeds the matrix pipe.  (A ring of 3 or 5 fragment pairs in flight, the
+        // first ones issued before the image is written, was measured at 6.4-6.7 ms per launch against 5.5: the longer live
+        // ranges push 100+ more registers into scratch in this phase, where the 96 GEMM1 accumulators are still live.)
+        const int nks = h ? 14 : 16;
+        const _Float16* wk0 = wcol + (size_t)(h ? 16 : 0) * (8 * 2 * 512);
+        const _Float16* ah0 = imgh + lrow * IMG_STRIDE + 8 * g;
+        const _Float16* al0 = imgl + lrow * IMG_STRIDE + 8 * g;
+        f16x8 wq[2][2];
+        wq[0][0] = *reinterpret_cast<const f16x8*>(wk0);
+        wq[0][1] = *reinterpret_cast<const f16x8*>(wk0 + 512);
+#define OVN_W2_STEP(SLOT, KS)                                                                                  \
+  {                                                                                                            \
+    if ((KS) + 1 < nks) {                                                                                      \
+      const _Float16* wk = wk0 + (size_t)((KS) + 1) * (8 * 2 * 512);                                           \
+      wq[(SLOT) ^ 1][0] = *reinterpret_cast<const f16x8*>(wk);                                                 \
+      wq[(SLOT) ^ 1][1] = *reinterpret_cast<const f16x8*>(wk + 512);                                           \
+    }                                                                                                          \
+    f16x8 fh[3], fl[3];                                                                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt) {                                                         \
+      fh[mt] = *reinterpret_cast<const f16x8*>(ah0 + mt * 16 * IMG_STRIDE + 32 * (KS));                        \
+      fl[mt] = *reinterpret_cast<const f16x8*>(al0 + mt * 16 * IMG_STRIDE + 32 * (KS));                        \
+    }                                                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                           \
+        acc2t[mt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[mt], wq[SLOT][0], acc2t[mt][0], 0, 0, 0);     \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                           \
+        acc2t[mt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[mt], wq[SLOT][0], acc2t[mt][1], 0, 0, 0);     \
+    _Pragma("unroll") for (int mt = 0; mt < 3; ++mt)                                                           \
+        acc2t[mt][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[mt], wq[SLOT][1], acc2t[mt][2], 0, 0, 0);     \
+  }
+#pragma unroll 1
+        for (int ks = 0; ks < nks; ks += 2) {   // nks is even
+          OVN_W2_STEP(0, ks)
+          OVN_W2_STEP(1, ks + 1)
+        }
+#undef OVN_W2_STEP
+      }
+      const int p = 16 * wave + lrow;
+      const float bv = b2[p];
+      float vmax = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 3; ++mt) {
+        const f32x4 a2v = (acc2t[mt][0] + acc2t[mt][1]) + acc2t[mt][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * mt + 4 * g + r;          // image row = 24 j + ib
+          const int j = m >= G ? 1 : 0;
+          const int ib2 = m - G * j;
+          const float v = fmaxf(fmaf(a2v[r], inv_2, bv), 0.0f);
+          if (ABL & 256) __builtin_nontemporal_store(v, o2 + (((long long)pair * G + ib2) * G + 2 * jb2 + j) * O2 + p);
+          else o2[(((long long)pair * G + ib2) * G + 2 * jb2 + j) * O2 + p] = v;
+          vmax = fmaxf(vmax, v);
+        }
+      }
+      // the pair's max c_conv2 output, for the scale of the fp16 split in c3_dense (non-negative floats order like their bits)
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+      if (lane == 0) atomicMax(o2max + pair, __float_as_uint(vmax));
+    }
+  }
+}
+
+#undef OVN_LOAD_L
+#undef OVN_SLICE
+#undef OVN_TILE_MFMA
+
+// =====================================================================================================================
+// SPLIT path: c_conv1 (the min-term contraction) and c_conv2 as two kernels.
+//
+// c_conv1 is LINEAR (generateNet.py:96-99, activation='linear'), so with |l - r| = l' + r' - 2 min(l', r') (l' = l + c, r' = r + c)
+//     o2pre[ib][jb][p] = b2[p] + TT[ib][p] + AA[jb][p] - 2 sum_{di,o} M[15 ib + di][jb][o] W2[di][o][p]
+//     M[i][jb][o]  = sum_{dj,c} min(l'[i][c], r'[15 jb + dj][c]) W1[dj][c][o]          <- delta_c1_f16x3_kernel (99.4 % of the work)
+//     TT[ib][p]    = sum_{di,o} (b1[o] + sum_c l'[15 ib + di][c] Ws[c][o]) W2[di][o][p]  <- per pair, prepare kernel
+//     AA[jb][p]    = sum_o (sum_{dj,c} r'[15 jb + dj][c] W1[dj][c][o]) W2s[o][p]        <- per pair, prepare kernel
+// The c_conv1 kernel then has NO epilogue phase: it stores -2 M (scaled) as fp32 and goes on with the next column groups, its
+// registers hold nothing but the 96 accumulators, one L slice and the operand fragments, and every operand stream (W1 window,
+// packed R rows, packed L slices) arrives by LDS-DMA (global_load_lds_dwordx4): no staging registers, no ds_write pass, no
+// exposed global-load latency.  c_conv2 becomes a streaming GEMM over the (n 576) x 960 matrix of -2 M rows
+// (delta_c2_f16x3_kernel, HBM-bound: 2.2 MB per pair).  In the fused kernel above the epilogue + c_conv2 phase cost 0.93 ms of
+// 5.5 (its MFMAs: 0.25), the exposed L loads 0.43, the W1 register staging 0.35.
 constexpr int R_PASS_WORDS = 2 * S * FC;            // packed R rows of one pass (two column groups): 3840 words = 15,360 B
 constexpr int LST_WAVE_BYTES = 6 * 1024;            // one wave's L slice: 3 row tiles x 2 x 16 B per lane
 constexpr int TT_STRIDE = K2 + 8;                   // fp16 elements per row of the T image in LDS (1936 B: 16-B reads of 16 rows spread over all banks)
@@ -479,7 +914,7 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 // (tile of 192 (jb, ib) rows, k-step major; K order of W2p: o' = 4 (o & 15) + (o >> 4)), 16 bytes per lane and accumulator row.
 // ABL (timing-only, -DOVN_ABLATE builds): 1 no o1 stores, 2 no W1 DMA, 4 no chunk barrier, 8 no L DMA / slice reads, 16 no R DMA,
 // 64 W1 DMA always from chunk 0 (cache-resident source), 128 o1 stores of every pair into 256 pairs' rows (cache-resident destination)
-template <int SPC, int ABL = 0>
+template <int SPC, bool PIN, int ABL = 0>
 __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __restrict__ pl, const unsigned* __restrict__ pr,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
                                                              float* __restrict__ o1raw, int rot, int nsplit) {
@@ -506,6 +941,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
   const float krow = scales[2 * pair][1];
   const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
   unsigned char* lmine = lst + wave * LST_WAVE_BYTES;
+  const bool has_t2 = (48 * wave + 32 < FW) || (ABL & 512);   // the 24th row tile (wave 7, t = 2) lies past the volume
 
   // lane's L source of tile t (rows past the volume re-read row 359: their accumulators are never stored)
   int lsrc[3];
@@ -517,8 +953,8 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
   }
 #define OVN_DMA_L(SL)                                                                            \
   _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                \
-    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t], lmine + (2 * t) * 1024);              \
-    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t] + 4, lmine + (2 * t + 1) * 1024);      \
+    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t], lmine + (2 * t) * 1024);                      \
+    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t] + 4, lmine + (2 * t + 1) * 1024);              \
   }
 #define OVN_DMA_W(CH, BUF)                                                                       \
   _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                \
@@ -526,7 +962,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
 #define OVN_DMA_R(PASS, BUF)                                                                     \
   {                                                                                              \
     const unsigned* rsrc = Rw + (size_t)(PASS) * R_PASS_WORDS;                                    \
-    glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);                    \
+    glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);                            \
     if (wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
   }
 
@@ -586,8 +1022,10 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
 #pragma unroll
         for (int h = 0; h < SPC; ++h) {
           if (h + 1 < SPC) OVN_READ_FRAGS((h + 1) & 1, h + 1)
+          if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
+            if (t == 2 && !has_t2) continue;   // wave-uniform: rows 368 .. 383 do not exist
             f16x8 ah, al;
             make_a(la[t][0], la[t][1], rw[h & 1][0], rw[h & 1][1], ah, al);
 #pragma unroll
@@ -648,6 +1086,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
 // (in-order return) never waits for the younger A loads.  Plain loads only: next to an LDS-DMA the compiler drains vmcnt(0)
 // at every barrier, which cuts the prefetch distance to one step (measured 0.60 ms; one step = the loaded HBM latency, ~3 us).
 // Epilogue: acc / (s1r sw2) + TT[ib] + AA[jb] + b2, ReLU, per-pair maximum.
+template <bool NT>
 __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __restrict__ o1raw, const _Float16* __restrict__ w2p,
                                                                          const float* __restrict__ lin, const f32x4* __restrict__ scales,
                                                                          float* __restrict__ o2, unsigned* __restrict__ o2max, float one,
@@ -667,8 +1106,13 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
   f32x4 wr[4];
 #define OVN_LOAD_A(SLOT, KS)                                                                 \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                        \
-    araw[SLOT][mt][0] = *reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512);       \
-    araw[SLOT][mt][1] = *reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512 + 4);   \
+    if (NT) {                                                                                                 \
+      araw[SLOT][mt][0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512));      \
+      araw[SLOT][mt][1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512 + 4));  \
+    } else {                                                                                                  \
+      araw[SLOT][mt][0] = *reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512);     \
+      araw[SLOT][mt][1] = *reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512 + 4); \
+    }                                                                                                         \
   }
 #define OVN_LOAD_W(KS) \
   _Pragma("unroll") for (int q = 0; q < 4; ++q) wr[q] = *reinterpret_cast<const f32x4*>(w2bytes + (size_t)(KS) * 16384 + q * 4096);
@@ -770,11 +1214,15 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
 
 }  // namespace
 
-size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
+size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right, bool split) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-  return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + 2 * al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
-         al((size_t)n * LIN_ELEMS * sizeof(float)) + al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float)) +
-         al((size_t)n * O1RAW_ELEMS * sizeof(float));
+  if (split)
+    return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + 2 * al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
+           al((size_t)n * LIN_ELEMS * sizeof(float)) + al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float)) +
+           al((size_t)n * O1RAW_ELEMS * sizeof(float));
+  return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
+         al((size_t)n * TL_ELEMS * sizeof(float)) + al((size_t)n * A2_ELEMS * sizeof(float)) +
+         al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float));
 }
 
 static int pick_nsplit(int n) {
@@ -790,9 +1238,9 @@ static int pick_nsplit(int n) {
   return 1;
 }
 
-// a2 + prepare (profile class delta_prep), c_conv1 contraction (delta_c12), c_conv2 GEMM (delta_c2)
-int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
+// split path: a2 + prepare (scope delta_prep), c_conv1 contraction (scope delta_c12), c_conv2 GEMM (scope delta_c2)
+static int delta_split_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
+                               int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel), PREP_SPLIT_LDS);
   if (rc) return rc;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -822,41 +1270,97 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-#define OVN_C1_LAUNCH(SPCV, ...)                                                                                             \
+    const int variant = getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0;
+#define OVN_C1_LAUNCH(SPCV, PINV, ...)                                                                                            \
   {                                                                                                                          \
     constexpr size_t lds = 2 * (size_t)(SPCV) * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;                          \
-    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), lds);              \
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, PINV, ##__VA_ARGS__>), lds);                      \
     if (rc) return rc;                                                                                                       \
-    hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, pl, pr,       \
+    hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, PINV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, pl, pr,               \
                        reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit);                             \
   }
+    switch (variant) {
+      case 1: OVN_C1_LAUNCH(3, true) break;
+      case 2: OVN_C1_LAUNCH(5, false) break;
+      case 3: OVN_C1_LAUNCH(5, true) break;
 #ifdef OVN_ABLATE
-    switch (getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0) {   // tools/experiments/c1_variants.py
-      case 2: OVN_C1_LAUNCH(5) break;
-      case 101: OVN_C1_LAUNCH(3, 1) break;
-      case 102: OVN_C1_LAUNCH(3, 2) break;
-      case 104: OVN_C1_LAUNCH(3, 4) break;
-      case 108: OVN_C1_LAUNCH(3, 8) break;
-      case 116: OVN_C1_LAUNCH(3, 16) break;
-      case 127: OVN_C1_LAUNCH(3, 27) break;
-      case 131: OVN_C1_LAUNCH(3, 31) break;
-      case 164: OVN_C1_LAUNCH(3, 64) break;
-      case 228: OVN_C1_LAUNCH(3, 128) break;
-      case 292: OVN_C1_LAUNCH(3, 192) break;
-      case 356: OVN_C1_LAUNCH(3, 256) break;
-      default: OVN_C1_LAUNCH(3) break;
-    }
-#else
-    OVN_C1_LAUNCH(3)
+      case 101: OVN_C1_LAUNCH(3, false, 1) break;
+      case 102: OVN_C1_LAUNCH(3, false, 2) break;
+      case 104: OVN_C1_LAUNCH(3, false, 4) break;
+      case 108: OVN_C1_LAUNCH(3, false, 8) break;
+      case 116: OVN_C1_LAUNCH(3, false, 16) break;
+      case 131: OVN_C1_LAUNCH(3, false, 31) break;
+      case 164: OVN_C1_LAUNCH(3, false, 64) break;
+      case 356: OVN_C1_LAUNCH(3, false, 256) break;
+      case 612: OVN_C1_LAUNCH(3, false, 512) break;
+      case 228: OVN_C1_LAUNCH(3, false, 128) break;
+      case 292: OVN_C1_LAUNCH(3, false, 192) break;
+      case 127: OVN_C1_LAUNCH(3, false, 27) break;
 #endif
+      default: OVN_C1_LAUNCH(3, false) break;
+    }
 #undef OVN_C1_LAUNCH
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_C2, stream);
     const int total_rows = n * G * G;
-    hipLaunchKernelGGL(delta_c2_f16x3_kernel, dim3(total_rows / C2_TILE_ROWS), dim3(256), 0, stream, o1raw,
-                       reinterpret_cast<const _Float16*>(ctx->w2p_h), lin, scales, o2, o2max, 1.0f, total_rows);
+    hipLaunchKernelGGL(delta_c2_f16x3_kernel<false>, dim3(total_rows / C2_TILE_ROWS), dim3(256), 0, stream, o1raw,
+                         reinterpret_cast<const _Float16*>(ctx->w2p_h), lin, scales, o2, o2max, 1.0f, total_rows);
   }
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
+  if (ctx->delta_split) return delta_split_forward(ctx, feats_l, lidx, feats_r, ridx, n, scratch, o2max_out, o2, stream);
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_kernel<3, 8>), LDS_BYTES);
+  if (rc) return rc;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  char* p = static_cast<char*>(scratch);
+  f32x4* scales = reinterpret_cast<f32x4*>(p);
+  p += al((size_t)n * 8 * sizeof(float));
+  unsigned* o2max = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * sizeof(unsigned));
+  unsigned* pl = reinterpret_cast<unsigned*>(p);
+  p += al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned));
+  float* tl = reinterpret_cast<float*>(p);
+  p += al((size_t)n * TL_ELEMS * sizeof(float));
+  float* a2s = reinterpret_cast<float*>(p);
+  p += al((size_t)n * A2_ELEMS * sizeof(float));
+  float* a2raw = reinterpret_cast<float*>(p);
+  *o2max_out = o2max;
+  const int nsplit = pick_nsplit(n);
+  {
+    OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
+    hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
+    hipLaunchKernelGGL(delta_prepare_kernel, dim3(n), dim3(512), 0, stream, feats_l, lidx, feats_r, ridx,
+                       reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1, a2raw, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.sws,
+                       ctx->hs.w1_colsum, ctx->hs.b1_absmax, scales, o2max, pl, tl, a2s);
+  }
+  OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+#define OVN_DELTA_LAUNCH(ABLV)                                                                                                  \
+  hipLaunchKernelGGL((delta_c12_f16x3_kernel<3, 8, ABLV>), dim3(n * nsplit), dim3(512), LDS_BYTES, stream, pl, tl, a2s, feats_r, ridx, \
+                     reinterpret_cast<const _Float16*>(ctx->w1p_h), reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->c2.bias,  \
+                     scales, o2, o2max, 1, nsplit)
+#ifdef OVN_ABLATE
+  {
+    const int abl = getenv("OVN_DELTA_ABL") ? atoi(getenv("OVN_DELTA_ABL")) : 0;
+#define OVN_ABL_CASE(V)                                                                                          \
+  case V:                                                                                                        \
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c12_f16x3_kernel<3, 8, V>), LDS_BYTES);       \
+    if (rc) return rc;                                                                                           \
+    OVN_DELTA_LAUNCH(V);                                                                                         \
+    break;
+    switch (abl) {
+      OVN_ABL_CASE(0) OVN_ABL_CASE(1) OVN_ABL_CASE(2) OVN_ABL_CASE(4) OVN_ABL_CASE(12) OVN_ABL_CASE(16) OVN_ABL_CASE(32)
+      OVN_ABL_CASE(64) OVN_ABL_CASE(67) OVN_ABL_CASE(79) OVN_ABL_CASE(95) OVN_ABL_CASE(128) OVN_ABL_CASE(129) OVN_ABL_CASE(195) OVN_ABL_CASE(256) OVN_ABL_CASE(257)
+      default: ovn_set_error("OVN_DELTA_ABL=%d not compiled", abl); return OVN_ERR_ARG;
+    }
+  }
+#else
+  OVN_DELTA_LAUNCH(0);
+#endif
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -888,7 +1392,9 @@ int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const floa
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1sum, (size_t)FC * O1 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1col, (size_t)O1 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc(&ctx->wsp_h, (size_t)FC * O1 * 2 * sizeof(_Float16)));
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->w2raw, (size_t)K2 * O2 * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->w2sum, (size_t)O1 * O2 * sizeof(float)));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->w2raw, c2_kernel_dev, (size_t)K2 * O2 * sizeof(float), hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(delta_w2sum_kernel, dim3((O1 * O2 + 255) / 256), dim3(256), 0, stream, c2_kernel_dev, ctx->w2sum);
   OVN_HIP_CHECK(hipMemcpyAsync(ctx->w1raw, c1_kernel_dev, (size_t)K1 * O1 * sizeof(float), hipMemcpyDeviceToDevice, stream));
   hipLaunchKernelGGL(delta_w1sum_kernel, dim3((FC * O1 + 255) / 256), dim3(256), 0, stream, c1_kernel_dev, ctx->w1sum, ctx->w1col);
