@@ -4,8 +4,8 @@
 // The generic implicit-GEMM kernel (conv_f16x3.hip) gathers every o2 element 18 times (9 taps x 2 column blocks), splits it
 // into hi/lo halves each time and pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a
 // workgroup owns a band of output rows of ONE pair (22 rows = bands of 8, 7, 7): its input patch ((rows+2) x 24 pixels x 128
-// channels) is loaded and split ONCE into an LDS-resident hi/lo image (one [pixel][8 fp16] plane per group of 8 channels,
-// planes a multiple of 256 B apart: conflict-free ds_read_b128, see conv_strip.hip), and the 3x3 taps are just address offsets into it -- no re-staging and no barrier
+// channels) is loaded and split ONCE into an LDS-resident hi/lo image (one [pixel][8 fp16] plane per group of 8 channels:
+// conflict-free ds_read_b128 per 16-lane group, see conv_strip.hip), and the 3x3 taps are just address offsets into it -- no re-staging and no barrier
 // in the 36-step K loop (9 taps x 4 channel chunks of 32).  The 8 waves split the 256 output channels (2 n-tiles each), every
 // wave walks all m-tiles (8 x 22 = 176 pixels = 11 exact tiles), 66 MFMAs per K step against 4 weight-fragment loads straight
 // from L2 (prefetched one step ahead).  The Dense dot product is taken in the epilogue on the accumulators (o3 never goes to
@@ -33,7 +33,8 @@ constexpr int NBAND = 3;                 // output-row bands per pair: [0,8) [8,
 constexpr int MAX_ROWS = 8;
 constexpr int MAX_MT = (MAX_ROWS * OW + 15) / 16;          // 11 m-tiles
 constexpr int IN_PIX_MAX = (MAX_ROWS + 2) * G;             // 240 input pixels
-constexpr int PLANE = IN_PIX_MAX * 8;                      // fp16 elements per 8-channel plane: [pixel][8], 3840 B = 15 x 256 B
+constexpr int PLANE = IN_PIX_MAX * 8 + 8;                  // fp16 elements per 8-channel plane: [pixel][8] + one 16-B slot, so that the 16
+                                                           // planes a wave writes at once start in different banks (3840 B apart they all hit bank 0)
 constexpr int NPL = CI / 8;                                // 16 planes
 constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 64;   // hi + lo images + reduction scratch
 constexpr int NW = 8;
@@ -75,20 +76,32 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   {
     const float* src = o2 + ((long long)pair * G + r0) * G * CI;     // rows r0 .. r0 + nrows + 1, contiguous in NHWC
     const int n4 = (nrows + 2) * G * CI / 4;
-    for (int i = tid; i < n4; i += 64 * NW) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * i);
-      const int pix = i / (CI / 4);
-      const int c = 4 * (i - pix * (CI / 4));
-      v4_t h, l;
+    // all of a thread's loads are issued before the first is used: one memory round trip per workgroup instead of fifteen
+    constexpr int PER_THREAD = (MAX_ROWS + 2) * G * CI / 4 / (64 * NW);   // 15
+    static_assert(PER_THREAD * 64 * NW == (MAX_ROWS + 2) * G * CI / 4, "patch does not divide over the threads");
+    f32x4 v[PER_THREAD];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float x = v[e] * s2;
-        h[e] = (elem_t)x;
-        l[e] = (elem_t)(x - (float)h[e]);
+    for (int k = 0; k < PER_THREAD; ++k) {
+      const int i = tid + k * (64 * NW);
+      v[k] = (i < n4) ? *reinterpret_cast<const f32x4*>(src + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int k = 0; k < PER_THREAD; ++k) {
+      const int i = tid + k * (64 * NW);
+      if (i < n4) {
+        const int pix = i / (CI / 4);
+        const int c = 4 * (i - pix * (CI / 4));
+        v4_t h, l;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = v[k][e] * s2;
+          h[e] = (elem_t)x;
+          l[e] = (elem_t)(x - (float)h[e]);
+        }
+        const int o = (c >> 3) * PLANE + pix * 8 + (c & 7);
+        *reinterpret_cast<v4_t*>(ih + o) = h;
+        *reinterpret_cast<v4_t*>(il + o) = l;
       }
-      const int o = (c >> 3) * PLANE + pix * 8 + (c & 7);
-      *reinterpret_cast<v4_t*>(ih + o) = h;
-      *reinterpret_cast<v4_t*>(il + o) = l;
     }
   }
 

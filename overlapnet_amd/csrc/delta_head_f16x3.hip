@@ -264,7 +264,7 @@ constexpr int TT_STRIDE = K2 + 8;                   // fp16 elements per row of 
 constexpr int LIN_ELEMS = 2 * G * O2;               // per pair: TT + b2 [24][128], AA [24][128]
 constexpr size_t O1RAW_ELEMS = (size_t)G * FW * O1; // per pair: 552,960 floats = 3 tiles of 192 (jb, ib) rows x 960
 constexpr int C2_TILE_ROWS = 192;                   // rows (jb % 8, ib) of one c_conv2 workgroup; o1raw is stored [tile][k-step][row][32]
-constexpr size_t PREP_SPLIT_LDS = 2 * (size_t)G * TT_STRIDE * sizeof(_Float16) + ((size_t)G * O1 + 2 * NWAVE) * sizeof(float);
+constexpr size_t PREP_SPLIT_LDS = 2 * (size_t)G * TT_STRIDE * sizeof(_Float16) + ((size_t)G * O1 + 2 * NWAVE) * sizeof(float) + (size_t)FC * O1 * 2 * sizeof(_Float16);
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   // LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16 l (the base is wave-uniform: it goes through M0)
@@ -275,8 +275,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // Per pair: value range -> shift and scales; both volumes packed ONCE into the word streams the c_conv1 kernel DMAs into LDS
 //   pl[pair][s(4)][i(360)][g(4)][8]       L words, channel slice major: lane (row, g) of slice s reads 32 contiguous bytes
 //   pr[pair][jb(24)][s(4)][dj(15)][g(4)][8] R words in the order of one pass's LDS image (two column groups = 15,360 B contiguous)
-// and the linear terms lin[pair] = {TT + b2 [24][128], AA [24][128]} (fp32 MFMA on the T image in LDS / plain FMAs).
+// and the linear terms lin[pair] = {TT + b2 [24][128], AA [24][128]} (fp16 MFMA on the T image in LDS / plain FMAs).
 // scales[2 pair] = {sa, -2 s1r / (sa sw1), s1r, 1 / (s1r sw2)}; s1r = scale of -2 M, bounded by 2 span max_o sum |W1[., o]|.
+// One workgroup per pair and one workgroup per CU (129 KB of LDS), so nothing hides a memory round trip: every phase issues ALL of
+// a thread's loads before it uses the first (the left volume stays in registers from the range scan to the packing; a loop of
+// load / use / load costs one round trip per iteration and made this kernel 0.33 ms per 1024 pairs instead of ~0.15).
 __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const float* __restrict__ feats_l, const int32_t* __restrict__ lidx, const float* __restrict__ feats_r,
     const int32_t* __restrict__ ridx, const _Float16* __restrict__ wsp, const float* __restrict__ w1col,
@@ -290,20 +293,81 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
   _Float16* Tlo = Th + G * TT_STRIDE;
   float* A2l = reinterpret_cast<float*>(Tlo + G * TT_STRIDE);   // [24][64]
   float* red = A2l + G * O1;                                    // [2][NWAVE]
+  _Float16* wsl = reinterpret_cast<_Float16*>(red + 2 * NWAVE); // Ws fragments [ks(4)][nt(4)][hl(2)][lane(64)][8]: 32 KB
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, g = lane >> 4;
   const float* Lf = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
   const float* Rf = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
-  const f32x4* L4 = reinterpret_cast<const f32x4*>(Lf);
   const f32x4* R4 = reinterpret_cast<const f32x4*>(Rf);
-  float mx = -3.0e38f, mn = 3.0e38f;
-  for (int i = tid; i < OVN_FEAT_ELEMS / 4; i += 512) {
-    const f32x4 a = L4[i], b = R4[i];
-    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3]))));
-    mn = fminf(mn, fminf(fminf(fminf(a[0], a[1]), fminf(a[2], a[3])), fminf(fminf(b[0], b[1]), fminf(b[2], b[3]))));
+
+  // ---- all loads of the first phase in flight at once ----
+  // L in MFMA A-fragment order: wave w, row tiles 3w .. 3w+2; a lane owns row lrow of the tile and channels 32 ks + 8 g .. + 7 of
+  // each 32-channel MFMA step, i.e. main-kernel lane group ks of slice g.  96 registers, kept until the words are packed.
+  f32x4 lv[3][4][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int i = 48 * wave + 16 * t + lrow;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (i < FW) {
+        const float* src = Lf + (size_t)i * FC + 32 * ks + 8 * g;
+        lv[t][ks][0] = *reinterpret_cast<const f32x4*>(src);
+        lv[t][ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
+      } else {
+        lv[t][ks][0] = lv[t][ks][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
+  // Ws fragments -> LDS (4 x 16 B per thread), A2 K slices (3 elements x 8 slices per thread)
+  f32x4 wsv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) wsv[q] = reinterpret_cast<const f32x4*>(wsp)[tid + 512 * q];
+  float a2v[3][A2_KSPLIT];
+  {
+    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_KSPLIT * A2_ELEMS;
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int k = 0; k < A2_KSPLIT; ++k) a2v[u][k] = src[(size_t)k * A2_ELEMS + tid + 512 * u];
+  }
+  // R: range scan now (12 x 32 B per thread, two batches of loads), packed in a second pass once the scale is known
+  constexpr int R_ITEMS = OVN_FEAT_ELEMS / 8;   // 5760 = 11.25 x 512
+  float mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    f32x4 rv[6][2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i8 = tid + 512 * (6 * half + k);
+      if (i8 < R_ITEMS) {
+        rv[k][0] = R4[2 * i8];
+        rv[k][1] = R4[2 * i8 + 1];
+      } else {
+        rv[k][0] = rv[k][1] = R4[0];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        mx = fmaxf(mx, fmaxf(fmaxf(rv[k][h][0], rv[k][h][1]), fmaxf(rv[k][h][2], rv[k][h][3])));
+        mn = fminf(mn, fminf(fminf(rv[k][h][0], rv[k][h][1]), fminf(rv[k][h][2], rv[k][h][3])));
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+    if (48 * wave + 16 * t + lrow < FW) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 a = lv[t][ks][h];
+          mx = fmaxf(mx, fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])));
+          mn = fminf(mn, fminf(fminf(a[0], a[1]), fminf(a[2], a[3])));
+        }
+    }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     mx = fmaxf(mx, __shfl_down(mx, off, 64));
@@ -313,6 +377,8 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     red[wave] = mx;
     red[NWAVE + wave] = mn;
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) reinterpret_cast<f32x4*>(wsl)[tid + 512 * q] = wsv[q];
   __syncthreads();
   mx = red[0];
   mn = red[NWAVE];
@@ -332,63 +398,78 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
     o2max[pair] = 0u;
   }
-  // A2[jb][o] of this pair (true units): sum of the K slices of delta_a2_kernel + c (column sums of W1)
-  {
-    const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_KSPLIT * A2_ELEMS;
-    for (int i = tid; i < A2_ELEMS; i += 512) {
-      float v = src[i];
+  // A2[jb][o] of this pair (true units): sum of the K slices of delta_a2_kernel (fixed order) + c (column sums of W1)
 #pragma unroll
-      for (int k = 1; k < A2_KSPLIT; ++k) v += src[(size_t)k * A2_ELEMS + i];
-      A2l[i] = v + c * w1col[i & (O1 - 1)];
-    }
+  for (int u = 0; u < 3; ++u) {
+    float v = a2v[u][0];
+#pragma unroll
+    for (int k = 1; k < A2_KSPLIT; ++k) v += a2v[u][k];
+    const int i = tid + 512 * u;
+    A2l[i] = v + c * w1col[i & (O1 - 1)];
   }
-  // R words in pass order
+  // R words in pass order (second read of R: L2 hits, all loads of a batch in flight)
   {
     unsigned* Pr = pr + (size_t)pair * OVN_FEAT_ELEMS;
-    for (int i8 = tid; i8 < OVN_FEAT_ELEMS / 8; i8 += 512) {
-      const int jrow = i8 >> 4, ch = (i8 & 15) * 8;
-      const int jb = jrow / S, dj = jrow - jb * S;
-      const int gm = ch >> 5, s = (ch & 31) >> 3;
-      unsigned* dst = Pr + ((jb * 4 + s) * S + dj) * 32 + gm * 8;
-      *reinterpret_cast<u32x4*>(dst) = pack4(R4[2 * i8], sa, csa);
-      *reinterpret_cast<u32x4*>(dst + 4) = pack4(R4[2 * i8 + 1], sa, csa);
-    }
-  }
-  // L: wave w, row tiles 3w .. 3w+2.  A lane owns row lrow of the tile and channels 32 ks + 8 g .. + 7 of each 32-channel MFMA
-  // step, i.e. main-kernel lane group ks of slice g.
-  unsigned* P = pl + (size_t)pair * OVN_FEAT_ELEMS;
-  const float inv_t = 1.0f / (sa * sws);
-#pragma unroll 1
-  for (int t = 0; t < 3; ++t) {
-    const int i = 48 * wave + 16 * t + lrow;
-    if (16 * (3 * wave + t) >= FW) break;   // wave-uniform: the 24th row tile does not exist
-    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    u32x4 w0[4], w1[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      if (i < FW) {
-        const float* src = Lf + (size_t)i * FC + 32 * ks + 8 * g;
-        w0[ks] = pack4(*reinterpret_cast<const f32x4*>(src), sa, csa);
-        w1[ks] = pack4(*reinterpret_cast<const f32x4*>(src + 4), sa, csa);
-        unsigned* dst = P + ((size_t)(g * FW + i) * 4 + ks) * 8;
-        *reinterpret_cast<u32x4*>(dst) = w0[ks];
-        *reinterpret_cast<u32x4*>(dst + 4) = w1[ks];
-      } else {
-        w0[ks] = w1[ks] = (u32x4){0u, 0u, 0u, 0u};
+    for (int half = 0; half < 2; ++half) {
+      f32x4 rv[6][2];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i8 = tid + 512 * (6 * half + k);
+        if (i8 < R_ITEMS) {
+          rv[k][0] = R4[2 * i8];
+          rv[k][1] = R4[2 * i8 + 1];
+        } else {
+          rv[k][0] = rv[k][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i8 = tid + 512 * (6 * half + k);
+        if (i8 < R_ITEMS) {
+          const int jrow = i8 >> 4, ch = (i8 & 15) * 8;
+          const int jb = jrow / S, dj = jrow - jb * S;
+          const int gm = ch >> 5, s = (ch & 31) >> 3;
+          unsigned* dst = Pr + ((jb * 4 + s) * S + dj) * 32 + gm * 8;
+          *reinterpret_cast<u32x4*>(dst) = pack4(rv[k][0], sa, csa);
+          *reinterpret_cast<u32x4*>(dst + 4) = pack4(rv[k][1], sa, csa);
+        }
       }
     }
+  }
+  // L words (from the registers) + T = b1 + (L + c) Ws on the fp16 matrix cores, Ws fragments from LDS
+  unsigned* P = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  const float inv_t = 1.0f / (sa * sws);
+  float add[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) add[nt] = b1[16 * nt + lrow];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int i = 48 * wave + 16 * t + lrow;
+    if (16 * (3 * wave + t) >= FW) continue;   // wave-uniform: the 24th row tile does not exist
+    f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      u32x4 w0, w1;
+      if (i < FW) {
+        w0 = pack4(lv[t][ks][0], sa, csa);
+        w1 = pack4(lv[t][ks][1], sa, csa);
+        unsigned* dst = P + ((size_t)(g * FW + i) * 4 + ks) * 8;
+        *reinterpret_cast<u32x4*>(dst) = w0;
+        *reinterpret_cast<u32x4*>(dst + 4) = w1;
+      } else {
+        w0 = w1 = (u32x4){0u, 0u, 0u, 0u};
+      }
       u32x4 h, q;
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
-        h[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x07060302u);
-        q[p] = __builtin_amdgcn_perm(w0[ks][2 * p + 1], w0[ks][2 * p], 0x05040100u);
-        h[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x07060302u);
-        q[2 + p] = __builtin_amdgcn_perm(w1[ks][2 * p + 1], w1[ks][2 * p], 0x05040100u);
+        h[p] = __builtin_amdgcn_perm(w0[2 * p + 1], w0[2 * p], 0x07060302u);
+        q[p] = __builtin_amdgcn_perm(w0[2 * p + 1], w0[2 * p], 0x05040100u);
+        h[2 + p] = __builtin_amdgcn_perm(w1[2 * p + 1], w1[2 * p], 0x07060302u);
+        q[2 + p] = __builtin_amdgcn_perm(w1[2 * p + 1], w1[2 * p], 0x05040100u);
       }
       const f16x8 ah = __builtin_bit_cast(f16x8, h), al = __builtin_bit_cast(f16x8, q);
-      const _Float16* wk = wsp + (size_t)ks * (4 * 2 * 512) + lane * 8;
+      const _Float16* wk = wsl + (size_t)ks * (4 * 2 * 512) + lane * 8;
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) {
         const f16x8 bh = *reinterpret_cast<const f16x8*>(wk + (nt * 2) * 512), bl = *reinterpret_cast<const f16x8*>(wk + (nt * 2 + 1) * 512);
@@ -398,9 +479,6 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
       }
     }
     // the words hold (L + c) sa, so acc / (sa sws) = (L + c) Ws already includes the shift term
-    float add[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) add[nt] = b1[16 * nt + lrow];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = 48 * wave + 16 * t + 4 * g + r;
@@ -415,6 +493,15 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
       }
     }
   }
+  // first batch of W2 fragments for TT and this thread's column of W2s for AA: in flight across the barrier
+  constexpr int TT_BATCH = 10;                                      // k-steps per batch of weight-fragment loads (80 registers)
+  const _Float16* wk2 = w2p + ((size_t)wave * 2) * 512 + lane * 8;   // [ks][nt(8)][hl][lane][8], this wave's n-tile
+  f16x8 bfr[TT_BATCH][2];
+#pragma unroll
+  for (int u = 0; u < TT_BATCH; ++u) {
+    bfr[u][0] = *reinterpret_cast<const f16x8*>(wk2 + (size_t)u * (8 * 2 * 512));
+    bfr[u][1] = *reinterpret_cast<const f16x8*>(wk2 + (size_t)u * (8 * 2 * 512) + 512);
+  }
   __syncthreads();
   float* lp = lin + (size_t)pair * LIN_ELEMS;
   // TT = T[24 x 960] W2[960 x 128] on the fp16 matrix cores (3-term split against W2p); wave = n-tile, both m-tiles
@@ -424,20 +511,26 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const _Float16* al0 = Tlo + lrow * TT_STRIDE + 8 * g;
     const _Float16* ah1 = Th + r1 * TT_STRIDE + 8 * g;
     const _Float16* al1 = Tlo + r1 * TT_STRIDE + 8 * g;
-    const _Float16* wk = w2p + ((size_t)wave * 2) * 512 + lane * 8;   // [ks][nt(8)][hl][lane][8]
     f32x4 acc[2][3] = {{{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}};
-#pragma unroll 6
-    for (int ks = 0; ks < K2 / 32; ++ks) {
-      const f16x8 bh = *reinterpret_cast<const f16x8*>(wk + (size_t)ks * (8 * 2 * 512));
-      const f16x8 bl = *reinterpret_cast<const f16x8*>(wk + (size_t)ks * (8 * 2 * 512) + 512);
-      const f16x8 a0h = *reinterpret_cast<const f16x8*>(ah0 + 32 * ks), a0l = *reinterpret_cast<const f16x8*>(al0 + 32 * ks);
-      const f16x8 a1h = *reinterpret_cast<const f16x8*>(ah1 + 32 * ks), a1l = *reinterpret_cast<const f16x8*>(al1 + 32 * ks);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bh, acc[0][0], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bh, acc[1][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, bh, acc[0][1], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh, acc[1][1], 0, 0, 0);
-      acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bl, acc[0][2], 0, 0, 0);
-      acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl, acc[1][2], 0, 0, 0);
+#pragma unroll
+    for (int kb = 0; kb < K2 / 32; kb += TT_BATCH) {
+#pragma unroll
+      for (int u = 0; u < TT_BATCH; ++u) {
+        const int ks = kb + u;
+        const f16x8 bh = bfr[u][0], bl = bfr[u][1];
+        const f16x8 a0h = *reinterpret_cast<const f16x8*>(ah0 + 32 * ks), a0l = *reinterpret_cast<const f16x8*>(al0 + 32 * ks);
+        const f16x8 a1h = *reinterpret_cast<const f16x8*>(ah1 + 32 * ks), a1l = *reinterpret_cast<const f16x8*>(al1 + 32 * ks);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bh, acc[0][0], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bh, acc[1][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0l, bh, acc[0][1], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1l, bh, acc[1][1], 0, 0, 0);
+        acc[0][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0h, bl, acc[0][2], 0, 0, 0);
+        acc[1][2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1h, bl, acc[1][2], 0, 0, 0);
+        if (ks + TT_BATCH < K2 / 32) {   // refill the slot for the next batch
+          bfr[u][0] = *reinterpret_cast<const f16x8*>(wk2 + (size_t)(ks + TT_BATCH) * (8 * 2 * 512));
+          bfr[u][1] = *reinterpret_cast<const f16x8*>(wk2 + (size_t)(ks + TT_BATCH) * (8 * 2 * 512) + 512);
+        }
+      }
     }
     const float bv = b2[16 * wave + lrow];
     const float inv_tt = 1.0f / (sT * sw2);
@@ -451,13 +544,19 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
       }
     }
   }
-  // AA[jb][p] = sum_o A2[jb][o] W2s[o][p]
-  for (int idx = tid; idx < G * O2; idx += 512) {
-    const int jb = idx >> 7, p = idx & (O2 - 1);
-    float s = 0.f;
-#pragma unroll 8
-    for (int o = 0; o < O1; ++o) s = fmaf(A2l[jb * O1 + o], w2sum[o * O2 + p], s);
-    lp[G * O2 + idx] = s;
+  // AA[jb][p] = sum_o A2[jb][o] W2s[o][p]: thread = (p, 6 consecutive jb); its column of W2s in registers (64 loads in flight)
+  {
+    const int p = tid & (O2 - 1), jb0 = 6 * (tid >> 7);
+    float wcol[O1];
+#pragma unroll
+    for (int o = 0; o < O1; ++o) wcol[o] = w2sum[o * O2 + p];
+    float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < O1; ++o)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) s[j] = fmaf(A2l[(jb0 + j) * O1 + o], wcol[o], s[j]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) lp[G * O2 + (jb0 + j) * O2 + p] = s[j];
   }
 }
 
