@@ -37,9 +37,11 @@ from overlapnet_amd import distributed as D  # noqa: E402
 from tools import synthetic as S  # noqa: E402
 from overlapnet_amd.engine import OvnEngine  # noqa: E402
 
-# algorithmic work of the dominant kernel (fused DeltaLayer + c_conv1 + c_conv2), SURVEY.md section 8a row a7:
-#   c_conv1 8640 x 1920 x 64 and c_conv2 576 x 960 x 128 multiply-adds per pair, FLOP = 2 * MAC
-DELTA_C12_FLOP_PER_PAIR = 2 * (8640 * 1920 * 64 + 576 * 960 * 128)
+# algorithmic work of the dominant kernel, SURVEY.md section 8a row a7: c_conv1 8640 x 1920 x 64 and c_conv2 576 x 960 x 128
+# multiply-adds per pair, FLOP = 2 * MAC.  fp32 mode: one fused kernel does both; f16x3 mode: the timed kernel
+# (delta_c1_f16x3_kernel) is DeltaLayer + c_conv1 only, c_conv2 is its own kernel (`kernels.delta_c2`, `delta_total_ms`).
+DELTA_C1_FLOP_PER_PAIR = 2 * 8640 * 1920 * 64
+DELTA_C2_FLOP_PER_PAIR = 2 * 576 * 960 * 128
 CAND_BYTES_PER_PAIR = 184_320 + 8           # candidate feature volume read once + (overlap, yaw) written
 SPEC_BYTES_PER_PAIR = 188_416 + 4           # what the spectral form streams: one cached spectrum (128 x 368 f32) + yaw
 LEG_FLOP_PER_SCAN = {1: 1637.5e6, 4: 1733.2e6, 5: 1765.1e6}
@@ -49,10 +51,12 @@ PEAK_HBM_BPS = 8.0e12
 
 HEAD_KERNEL = {
     "f32": ("delta_c12_kernel (DeltaLayer+c_conv1+c_conv2, fp32 MFMA)", PEAK_F32_MFMA_TFLOPS, "delta_c12_kernel",
-            "fp32 matrix cores, one MFMA per product"),
-    "f16x3": ("delta_c12_f16x3_kernel (DeltaLayer+c_conv1+c_conv2, fp16 MFMA)", PEAK_16BIT_MFMA_TFLOPS, "delta_c12_f16x3",
-              "achieved counts ALGORITHMIC flops; the 3-term split issues 3 MFMA flops per algorithmic flop, so the matrix "
-              "pipe executes 3x this rate (frac <= 1/3 by construction)"),
+            DELTA_C1_FLOP_PER_PAIR + DELTA_C2_FLOP_PER_PAIR, "fp32 matrix cores, one MFMA per product"),
+    "f16x3": ("delta_c1_f16x3_kernel (DeltaLayer in min form + c_conv1, fp16 MFMA)", PEAK_16BIT_MFMA_TFLOPS, "delta_c1_f16x3",
+              DELTA_C1_FLOP_PER_PAIR,
+              "achieved counts ALGORITHMIC flops of DeltaLayer + c_conv1 (93.8 % of the Delta head's flops; c_conv2 and the linear "
+              "terms run in delta_c2 / delta_prep, see kernels); the 3-term split issues 3 MFMA flops per algorithmic flop, so "
+              "the matrix pipe executes 3x this rate (frac <= 1/3 by construction)"),
 }
 DTYPE_LABEL = {
     "f32": "f32",
@@ -346,8 +350,8 @@ def main():
     if d_n:
         # launches of one step: ceil(P / 2048) of up to 2048 pairs; the average launch carries P * steps / d_n pairs
         launch_pairs = P * args.steps / d_n
-    achieved = DELTA_C12_FLOP_PER_PAIR * launch_pairs / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
-    kname, peak, kprefix, rl_note = HEAD_KERNEL[args.head_precision]
+    kname, peak, kprefix, flop_per_pair, rl_note = HEAD_KERNEL[args.head_precision]
+    achieved = flop_per_pair * launch_pairs / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
     if strong:
         workload = ("1-vs-%d synthetic candidate pool sharded over %d rank(s) in contiguous blocks (BASELINE configs[3]; warm: 1 query "
                     "leg per rank + %d head pairs per step in total), feature volumes generated on the device, 64x900x%d query"
@@ -370,8 +374,10 @@ def main():
                    "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": rocprof_traffic(kprefix),
-                     "flop_per_launch": DELTA_C12_FLOP_PER_PAIR * launch_pairs, "pairs_per_launch": launch_pairs,
-                     "avg_launch_ms": avg_ms, "note": rl_note},
+                     "flop_per_launch": flop_per_pair * launch_pairs, "pairs_per_launch": launch_pairs,
+                     "avg_launch_ms": avg_ms,
+                     "delta_total_ms": sum(prof[k][0] / max(prof[k][1], 1) for k in ("delta_prep", "delta_c12", "delta_c2") if k in prof),
+                     "note": rl_note},
         "kernels": kernel_table(prof),
         "head_hbm_gbps_algorithmic": (pairs / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
     }

@@ -34,7 +34,8 @@ constexpr int MAX_ROWS = 8;
 constexpr int MAX_MT = (MAX_ROWS * OW + 15) / 16;          // 11 m-tiles
 constexpr int IN_PIX_MAX = (MAX_ROWS + 2) * G;             // 240 input pixels
 constexpr int PLANE = IN_PIX_MAX * 8 + 8;                  // fp16 elements per 8-channel plane: [pixel][8] + one 16-B slot, so that the 16
-                                                           // planes a wave writes at once start in different banks (3840 B apart they all hit bank 0)
+                                                           // planes a wave writes at once start in different banks (3840 B apart they all hit
+                                                           // bank 0; the fragment reads are unaffected: 0.637 -> 0.625 ms in one run)
 constexpr int NPL = CI / 8;                                // 16 planes
 constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 64;   // hi + lo images + reduction scratch
 constexpr int NW = 8;

@@ -51,19 +51,19 @@ def main():
         m = re.search(r'"avg_launch_ms": ([0-9.]+)', open(logp, errors="ignore").read())
         ev = float(m.group(1)) * 1e3 if m else None
     out["timed_launches"] = {}
-    for (name,) in con.execute("select distinct name from kernels where name like '%delta_c12%' or name like '%c3_dense%'").fetchall():
+    for (name,) in con.execute("select distinct name from kernels where name like '%delta_c1%' or name like '%delta_c2_%' or name like '%delta_prepare%' or name like '%c3_dense%'").fetchall():
         d = [r[0] for r in con.execute("select duration from kernels where name = ? order by start", (name,)).fetchall()]
         last = d[-5:]
         avg = sum(last) / len(last) / 1e3
         out["timed_launches"][short(name)] = {"avg_us_last5": avg, "dispatches": len(d)}
-        lines.append("| `%s` | %.2f | %s |" % (short(name), avg, ("%.2f" % ev) if (ev and "delta_c12" in name) else "-"))
+        lines.append("| `%s` | %.2f | %s |" % (short(name), avg, ("%.2f" % ev) if (ev and ("delta_c12" in name or "delta_c1_" in name)) else "-"))
     # per-dispatch geometry of our kernels
     geo = con.execute("select name, max(grid_x), max(workgroup_x), max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), "
                       "max(lds_size) from kernels group by name").fetchall()
     lines += ["", "| kernel | grid_x (max) | wg | vgpr | agpr | sgpr | lds B |", "|---|---|---|---|---|---|---|"]
     for g in geo:
         lines.append("| `%s` | %s | %s | %s | %s | %s | %s |" % ((short(g[0]),) + tuple(g[1:])))
-    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma"):
+    for sub in ("pmc_fetch", "pmc_write", "pmc_mfma", "pmc_clk"):
         p = os.path.join(src, sub, "bench_results.db")
         if not os.path.isfile(p):
             continue
