@@ -11,8 +11,9 @@
 //
 //   spectrum layout per scan: [c = 0..127][368] floats: Re X^[f,c] at [f], Im X^[f,c] at [184 + f], f = 0..180,
 //   columns 181..183 and 365..367 are zero padding (keeps every row 16-byte aligned for float4 loads).
-//   * ovn_spectrum:  the DFT is a dense contraction with a constant 360 x 368 twiddle matrix -> run on the fp32
-//     matrix cores through the generic conv kernel (a 360x1 'valid' convolution over the (360,128) feature image).
+//   * ovn_spectrum:  the DFT is a dense contraction with a constant 360 x 368 twiddle matrix: dft_f16x3_kernel (scaled fp16
+//     hi/lo split on the fp16 matrix cores, default) or, in the fp32 head mode, the generic fp32 conv kernel (a 360x1 'valid'
+//     convolution over the (360,128) feature image).
 //   * spectral_product_kernel: one workgroup per pair, thread = (4 consecutive frequencies, 32 channels); partial
 //     sums of the 4 channel groups are combined in LDS in a fixed order (deterministic).
 //   * the inverse transform of the 368-vector C^ is again a constant contraction (1x1 conv, 368 -> 368) and the
@@ -123,7 +124,148 @@ __global__ __launch_bounds__(256) void corr_argmax_kernel(const float* __restric
   }
 }
 
-int upload_layer(OvnConvLayer* L, const std::vector<float>& w, hipStream_t stream) {
+
+// ---- forward DFT on the fp16 matrix cores (f16x3 arithmetic, see delta_head_f16x3.hip) -------------------------------------------
+// spectra[scan][c][col] = sum_i X[scan][i][c] T[i][col]: per scan a (128 x 360) x (360 x 368) product whose A operand is the
+// TRANSPOSE of the feature image.  Workgroup = (scan, half of the channels): the 360 x 64 slab is read in items of 4 channels x
+// 8 rows (all of a thread's loads in flight), scaled by a power of two from its own largest |value|, split into fp16 hi / lo and
+// written transposed into LDS with 16-byte stores ([channel][i], rows 784 B apart: the 16 rows of an A-fragment read start in 16
+// different bank groups);
+// 8 waves x (4 m-tiles x 3 n-tiles), 12 K steps of 32 (i >= 360: zero twiddles against zeroed LDS columns), twiddle fragments
+// straight from L2 one step ahead.  The generic fp32 conv kernel gathers the strided operand element by element: 85 us per
+// 128 scans against ~15 here.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr int DFT_CH = 64;                 // channels per workgroup
+constexpr int DFT_KS = (FW + 31) / 32;     // 12 K steps
+constexpr int DFT_LD = 392;                // fp16 elements per LDS row (>= 384; 196 dwords = 4 mod 64)
+constexpr int DFT_NT = SWP / 16;           // 24 n-tiles
+constexpr size_t DFT_LDS = 2 * (size_t)DFT_CH * DFT_LD * sizeof(_Float16) + 64;
+
+// NTW n-tiles per wave: 3 (one workgroup covers all 24 n-tiles) or 1 (three workgroups per slab, blockIdx.y: a handful of scans
+// then still fills 6 x as many CUs; the slab staging is repeated, the K loop is a third as long)
+template <int NTW>
+__global__ __launch_bounds__(512) void dft_f16x3_kernel(const float* __restrict__ feats, const _Float16* __restrict__ tw,
+                                                       float sT, float one, float* __restrict__ spectra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
+  _Float16* ah = reinterpret_cast<_Float16*>(dsm);
+  _Float16* al = ah + DFT_CH * DFT_LD;
+  float* red = reinterpret_cast<float*>(al + DFT_CH * DFT_LD);
+  const int scan = blockIdx.x >> 1, half = blockIdx.x & 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lrow = lane & 15, g = lane >> 4;
+  const float* X = feats + (size_t)scan * OVN_FEAT_ELEMS + DFT_CH * half;
+
+  // slab -> registers.  Item = (4 channels, 8 consecutive rows i): 16 x 45 = 720 items, two per thread (the second round is
+  // partial); a lane then owns 8 consecutive K positions of 4 channel rows = one 16-byte LDS write per row and image.
+  constexpr int NITEM = (DFT_CH / 4) * (FW / 8);   // 720
+  f32x4 v[2][8];
+  float m = 0.f;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = tid + 512 * k;
+    const int cq = item & 15, ib = (item < NITEM) ? (item >> 4) : 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[k][j] = *reinterpret_cast<const f32x4*>(X + (size_t)(8 * ib + j) * FC + 4 * cq);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[k][j][0]), fabsf(v[k][j][1])), fmaxf(fabsf(v[k][j][2]), fabsf(v[k][j][3]))));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+  if (lane == 0) red[wave] = m;
+  // zero the K padding columns i = 360 .. 383 of every row (64 rows x 24 columns x hi/lo = 3 x 16 B per row and image)
+  if (tid < DFT_CH * 3 * 2) {
+    const int img = tid / (DFT_CH * 3), r = (tid / 3) % DFT_CH, q = tid % 3;
+    *reinterpret_cast<f32x4*>((img ? al : ah) + r * DFT_LD + FW + 8 * q) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  __syncthreads();
+  m = red[0];
+#pragma unroll
+  for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+  const float sx = ovn_pow2_scale_for(m);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int item = tid + 512 * k;
+    if (item < NITEM) {
+      const int cq = item & 15, ib = item >> 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // channel 4 cq + e: K positions 8 ib .. 8 ib + 7
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+          const float x0 = v[k][j][e] * sx, x1 = v[k][j + 1][e] * sx;
+          const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+          f16x2 lp;
+          lp[0] = (_Float16)__builtin_fmaf(x0, one, -(float)hp[0]);
+          lp[1] = (_Float16)__builtin_fmaf(x1, one, -(float)hp[1]);
+          hw[j >> 1] = __builtin_bit_cast(unsigned, hp);
+          lw[j >> 1] = __builtin_bit_cast(unsigned, lp);
+        }
+        typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<u32x4v*>(ah + (4 * cq + e) * DFT_LD + 8 * ib) = (u32x4v){hw[0], hw[1], hw[2], hw[3]};
+        *reinterpret_cast<u32x4v*>(al + (4 * cq + e) * DFT_LD + 8 * ib) = (u32x4v){lw[0], lw[1], lw[2], lw[3]};
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc[4][NTW];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[mt][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // twiddle fragments [ks][nt(24)][hi,lo][lane][8]; this wave's n-tiles nt0 .. nt0 + NTW - 1
+  const int nt0 = NTW * (8 * blockIdx.y + wave);
+  const _Float16* tsrc = tw + ((size_t)nt0 * 2) * 512 + lane * 8;
+  // an L2 round trip is ~3 K steps long (36 MFMAs each): fragments of three steps ahead are in flight (ring of 4 slots)
+  f16x8 bq[4][NTW][2];
+#define DFT_LOAD_B(SLOT, KS)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < NTW; ++j) {                                              \
+    const _Float16* q = tsrc + (size_t)(KS) * (DFT_NT * 2 * 512) + j * 1024;                     \
+    bq[SLOT][j][0] = *reinterpret_cast<const f16x8*>(q);                                         \
+    bq[SLOT][j][1] = *reinterpret_cast<const f16x8*>(q + 512);                                   \
+  }
+  DFT_LOAD_B(0, 0)
+  DFT_LOAD_B(1, 1)
+  DFT_LOAD_B(2, 2)
+#pragma unroll
+  for (int ks = 0; ks < DFT_KS; ++ks) {
+    if (ks + 3 < DFT_KS) DFT_LOAD_B((ks + 3) & 3, ks + 3)
+    f16x8 fh[4], fl[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      fh[mt] = *reinterpret_cast<const f16x8*>(ah + (16 * mt + lrow) * DFT_LD + 32 * ks + 8 * g);
+      fl[mt] = *reinterpret_cast<const f16x8*>(al + (16 * mt + lrow) * DFT_LD + 32 * ks + 8 * g);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[mt], bq[ks & 3][j][0], acc[mt][j], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[mt], bq[ks & 3][j][0], acc[mt][j], 0, 0, 0);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[mt][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[mt], bq[ks & 3][j][1], acc[mt][j], 0, 0, 0);
+    }
+  }
+#undef DFT_LOAD_B
+  // C/D layout: lane holds column lrow of its n-tile, rows (channels) 4g .. 4g+3 of each m-tile
+  const float inv = 1.0f / (sx * sT);
+  float* out = spectra + (size_t)scan * OVN_SPEC_ELEMS + (size_t)(DFT_CH * half) * SW;
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int col = 16 * (nt0 + j) + lrow;
+    if (col < SW) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)(16 * mt + 4 * g + r) * SW + col] = acc[mt][j][r] * inv;
+    }
+  }
+}
+
+int upload_layer(OvnConvLayer* L, const std::vector<float>& w, hipStream_t stream, bool f16 = false) {
   float* dw = nullptr;
   float* db = nullptr;
   OVN_HIP_CHECK(hipMalloc((void**)&dw, w.size() * sizeof(float)));
@@ -131,6 +273,7 @@ int upload_layer(OvnConvLayer* L, const std::vector<float>& w, hipStream_t strea
   OVN_HIP_CHECK(hipMemcpyAsync(dw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, stream));
   OVN_HIP_CHECK(hipMemsetAsync(db, 0, (size_t)L->cout * sizeof(float), stream));
   int rc = ovn_conv_prepare(L, dw, db, stream);  // synchronises the stream
+  if (rc == OVN_OK && f16) rc = ovn_conv_prepare_f16x3(L, dw, stream);   // + scaled fp16 hi/lo fragments (dft_f16x3_kernel)
   (void)hipFree(dw);
   (void)hipFree(db);
   return rc;
@@ -160,7 +303,7 @@ int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream) {
         w[(size_t)i * SWP + f] = (float)cos(ang);
         w[(size_t)i * SWP + IM_OFF + f] = (float)(-sin(ang));
       }
-    int rc = upload_layer(&L, w, stream);
+    int rc = upload_layer(&L, w, stream, true);
     if (rc) return rc;
   }
   {  // inverse transform of the Hermitian half, shifted by W/2 (RangePadding2D), as a (1,1,368,368) convolution
@@ -191,6 +334,20 @@ int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream) {
 }
 
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream) {
+  if (ctx->head_mode != 0) {   // f16x3 arithmetic (default)
+    int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(dft_f16x3_kernel<3>), DFT_LDS);
+    if (rc) return rc;
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(dft_f16x3_kernel<1>), DFT_LDS);
+    if (rc) return rc;
+    if (n <= 64)   // up to 128 slabs: three workgroups per slab
+      hipLaunchKernelGGL(dft_f16x3_kernel<1>, dim3(2 * n, 3), dim3(512), DFT_LDS, stream, feats,
+                         reinterpret_cast<const _Float16*>(ctx->dft.wp_h), ctx->dft.sw_h, 1.0f, spectra);
+    else
+      hipLaunchKernelGGL(dft_f16x3_kernel<3>, dim3(2 * n), dim3(512), DFT_LDS, stream, feats,
+                         reinterpret_cast<const _Float16*>(ctx->dft.wp_h), ctx->dft.sw_h, 1.0f, spectra);
+    OVN_HIP_CHECK(hipGetLastError());
+    return OVN_OK;
+  }
   int oh = 0, ow = 0;
   // input viewed as (n, H=360, W=128, C=1): out (n, 1, 128, 368) = spectra (n, 128, 368)
   return ovn_conv_forward(ctx->dft, feats, n, FW, FC, spectra, &oh, &ow, stream);
