@@ -261,6 +261,14 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       const bool last = (li + 1 == ctx->leg.size());
       float* dst = last ? features_dev + (size_t)s0 * OVN_FEAT_ELEMS : buf[li & 1];
       int oh = 0, ow = 0;
+      // batched f16x3 calls: the six 1 x KW layers at the end run as one kernel with the activations kept in LDS (the choice is
+      // per call, like the strip kernels', so that every scan of a call takes the same code path)
+      if (ctx->leg_mode != 0 && n > 8 && ovn_leg_tail_matches(ctx, li, h, w)) {
+        OvnProfScope ps(ctx, OVN_K_LEG, stream);
+        rc = ovn_leg_tail_forward(ctx, li, cur, nb, w, features_dev + (size_t)s0 * OVN_FEAT_ELEMS, stream);
+        if (rc) return rc;
+        break;
+      }
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)

@@ -228,6 +228,10 @@ int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra
 int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out,
                        const unsigned* in_max, unsigned* out_max, hipStream_t stream);
 
+// leg_tail.hip: the last six leg layers (1 x {9,9,9,7,5,3}, 128 -> 128) fused, activations carried through LDS (f16x3, batched calls)
+bool ovn_leg_tail_matches(const ovn_ctx* ctx, size_t first, int h, int w);
+int ovn_leg_tail_forward(const ovn_ctx* ctx, size_t first, const float* in, int nb, int w, float* out, hipStream_t stream);
+
 // c3_dense.hip: c_conv3 + Flatten + Dense fused (f16x3 mode), input patch resident in LDS
 // o2max: the per-pair maxima of o2 left by the f16x3 Delta kernel (scale of the fp16 split)
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
