@@ -454,6 +454,16 @@ def test_spectral_correlation_head(engines):
     assert _rel(sp[:, :, :181], np.transpose(ref.real, (0, 2, 1))) < 5e-6
     assert _rel(sp[:, :, 184:365], np.transpose(ref.imag, (0, 2, 1))) < 5e-6
     assert np.all(sp[:, :, 181:184] == 0) and np.all(sp[:, :, 365:] == 0)
+    # big calls use one workgroup per (scan, channel half), small ones three: same spectrum bit for bit; fp32 head mode = the
+    # fp32 conv-kernel form of the same transform
+    big = e.spectrum(ft[torch.arange(70) % 7].contiguous())
+    assert torch.equal(big[:7], spec) and torch.equal(big[63:70], spec)
+    e.set_head_precision("f32")
+    try:
+        sp32 = e.spectrum(ft).cpu().numpy()
+    finally:
+        e.set_head_precision(DEFAULT_HEAD)
+    assert _rel(sp32, sp) < 5e-6
     pairs = np.array([[i, j] for i in range(7) for j in (0, 2, 4)])
     r = e.corr_head_spectral(spec, spec, lidx=pairs[:, 0], ridx=pairs[:, 1], want_corr=True)
     d = e.corr_head(ft, ft, lidx=pairs[:, 0], ridx=pairs[:, 1], want_corr=True)
