@@ -217,27 +217,33 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
 // consecutive 16-byte slots, conflict-free.  The generic implicit-GEMM kernel re-gathers and re-splits every input element for
 // each of the ~19 (s_conv1) / ~22 (s_conv2) output positions that use it and, with only 1 / 2 n-tiles to amortise a split over,
 // ran these two layers at 3 % of the MFMA rate: 46 % of the batched leg's time.
-template <int CIN, int KH, int KW, int SW, int TW, int NT>
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS>
 struct SmallCfg {
   static constexpr int TPS = 32 / CIN;                       // taps per K step
   static constexpr int KSR = 16 / TPS;                       // K steps per kernel row (taps padded to 16)
   static constexpr int NK = KH * KSR;
   static constexpr int PIXA = SW * (TW - 1) + 16 + 8;        // strip pixels per row: last m-tile's last pixel + 16 taps (+ slack)
-  static constexpr int MT = TW / 16;
+  static constexpr int KHS = KH + SH * (ROWS - 1);           // strip rows: ROWS output rows share KH - SH input rows with their neighbour
+  static constexpr int MTR = TW / 16;                        // m-tiles per output row
+  static constexpr int MT = ROWS * MTR;
   static constexpr int MSPLIT = 8 / NT;
   static constexpr int MTH = (MT + MSPLIT - 1) / MSPLIT;
-  static constexpr size_t LDS_BYTES = 2 * (size_t)KH * PIXA * CIN * sizeof(_Float16);
+  static constexpr size_t LDS_BYTES = 2 * (size_t)KHS * PIXA * CIN * sizeof(_Float16);
   static_assert(TW % 16 == 0 && 32 % CIN == 0 && CIN % 4 == 0 && KW <= 16, "tile / channel constraints");
 };
 
-template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT>
+// ROWS consecutive output rows per workgroup: with stride SH < KH they share input rows, so the strip (the part of these
+// kernels that is not hidden: 52 MFMAs per wave against a 38 KB strip at ROWS = 1) is KH + SH (ROWS - 1) rows instead of KH ROWS.
+// s_conv1: 3 rows per block (9 strip rows for 15), s_conv2: 2 (5 for 6): batched leg 6.50 -> 6.05 ms per 1025 scans, almost all
+// of it from s_conv2; same K order per accumulator as ROWS = 1, bit-identical results.
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS>
 __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
-  typedef SmallCfg<CIN, KH, KW, SW, TW, NT> C;
+  typedef SmallCfg<CIN, KH, SH, KW, SW, TW, NT, ROWS> C;
   constexpr int COUT = 16 * NT;
-  constexpr int PIXA = C::PIXA, MTH = C::MTH, NK = C::NK, TPS = C::TPS, KSR = C::KSR;
+  constexpr int PIXA = C::PIXA, MTH = C::MTH, NK = C::NK, TPS = C::TPS, KSR = C::KSR, KHS = C::KHS, MTR = C::MTR;
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
   _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
-  _Float16* sl = sh + KH * PIXA * CIN;
+  _Float16* sl = sh + KHS * PIXA * CIN;
   const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
   const float inv = 1.0f / (s_in * a.sw);
   const float one = a.one;
@@ -253,8 +259,9 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   int bid = blockIdx.x;
   const int xt = bid % a.XT;
   bid /= a.XT;
-  const int oy = bid % a.OH;
-  const int b = bid / a.OH;
+  const int ohb = (a.OH + ROWS - 1) / ROWS;                    // row blocks per image
+  const int oy = ROWS * (bid % ohb);                           // first output row of the block
+  const int b = bid / ohb;
   const int x0 = xt * TW;                                      // first output pixel of the tile
   const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;
   const int px0 = SW * x0;                                     // first input pixel of the strip
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   // ---- strip -> LDS, scaled and split once ----
   {
     constexpr int Q = CIN / 4;
-    constexpr int TOTAL = KH * PIXA * Q;
+    constexpr int TOTAL = KHS * PIXA * Q;
     constexpr int ITERS = (TOTAL + 511) / 512;
     constexpr int BATCH = 4;
 #pragma unroll 1
@@ -278,7 +285,8 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
           const int r = i - row * (PIXA * Q);
           const int pix = r / Q;
           const int c = 4 * (r - pix * Q);
-          if (pix < pixv) v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + px0 + pix) * CIN + c);
+          if (pix < pixv && SH * oy + row < a.H)   // rows past the image belong to output rows past OH (odd row counts)
+            v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + px0 + pix) * CIN + c);
         }
       }
 #pragma unroll
@@ -304,8 +312,15 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
 
   // per-lane fragment base: output pixel lrow of the wave's first m-tile, k offset of lane group g
   const int goff = ((8 * g) / CIN) * CIN + (8 * g) % CIN;       // = 8 g: pixel-major makes (pixel, channel) linear
-  const _Float16* ah_base = sh + (SW * (16 * wm * MTH + lrow)) * CIN + goff;
-  const _Float16* al_base = sl + (SW * (16 * wm * MTH + lrow)) * CIN + goff;
+  // m-tile t = wm MTH + i covers output row t / MTR of the block, pixels 16 (t % MTR) ..; tiles past the block re-read tile 0
+  int aoff[MTH];
+#pragma unroll
+  for (int i = 0; i < MTH; ++i) {
+    int t = wm * MTH + i;
+    t = t < C::MT ? t : 0;
+    const int ry = t / MTR, mt = t - ry * MTR;
+    aoff[i] = (ry * SH * PIXA + SW * (16 * mt + lrow)) * CIN + goff;
+  }
   f32x4 acc[MTH];
 #pragma unroll
   for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -320,8 +335,8 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
     f16x8 fh[MTH], fl[MTH];
 #pragma unroll
     for (int i = 0; i < MTH; ++i) {
-      fh[i] = *reinterpret_cast<const f16x8*>(ah_base + toff + i * 16 * SW * CIN);
-      fl[i] = *reinterpret_cast<const f16x8*>(al_base + toff + i * 16 * SW * CIN);
+      fh[i] = *reinterpret_cast<const f16x8*>(sh + aoff[i] + toff);
+      fl[i] = *reinterpret_cast<const f16x8*>(sl + aoff[i] + toff);
     }
 #pragma unroll
     for (int i = 0; i < MTH; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bh, acc[i], 0, 0, 0);
@@ -333,14 +348,16 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
 
   const int n = 16 * wn + lrow;
   const float bv = a.bias[n];
-  float* orow = a.out + (((long long)b * a.OH + oy) * a.OW + x0) * COUT;
   float vmax = 0.f;
 #pragma unroll
   for (int i = 0; i < MTH; ++i) {
+    const int t = wm * MTH + i;
+    const int ry = t / MTR, mt = t - ry * MTR;
+    float* orow = a.out + (((long long)b * a.OH + oy + ry) * a.OW + x0) * COUT;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int p = 16 * (wm * MTH + i) + 4 * g + r;
-      if (p < tw && wm * MTH + i < C::MT) {
+      const int p = 16 * mt + 4 * g + r;
+      if (p < tw && t < C::MT && oy + ry < a.OH) {
         const float v = fmaxf(fmaf(acc[i][r], inv, bv), 0.0f);
         orow[(long long)p * COUT + n] = v;
         vmax = fmaxf(vmax, v);
@@ -355,10 +372,10 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   }
 }
 
-template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT>
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS>
 int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out, const unsigned* in_max,
                        unsigned* out_max, hipStream_t stream, bool* took) {
-  typedef SmallCfg<CIN, KH, KW, SW, TW, NT> C;
+  typedef SmallCfg<CIN, KH, SH, KW, SW, TW, NT, ROWS> C;
   StripArgs a;
   a.in = in;
   a.wp = reinterpret_cast<const _Float16*>(L.wp_h16);
@@ -373,12 +390,12 @@ int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long
   a.OH = (h - KH) / SH + 1;
   a.OW = (w - KW) / SW + 1;
   a.XT = (a.OW + TW - 1) / TW;
-  const long long wgs = (long long)nb * a.OH * a.XT;
+  const long long wgs = (long long)nb * ((a.OH + ROWS - 1) / ROWS) * a.XT;
   *took = call_nb * a.OH * a.XT >= 384;
   if (!*took) return OVN_OK;
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT>), C::LDS_BYTES);
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS>), C::LDS_BYTES);
   if (rc) return rc;
-  hipLaunchKernelGGL((conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -426,9 +443,9 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
   int rc = OVN_OK;
   if (L.wp_h16 != nullptr) {   // few input channels: pixel-major strips, taps padded to 16
     if (L.kh == 5 && L.kw == 15 && L.cin == 4 && L.cout == 16 && L.sh == 2 && L.sw == 2)          // s_conv1 at C = 4
-      rc = launch_strip_small<4, 5, 2, 15, 2, 224, 1>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      rc = launch_strip_small<4, 5, 2, 15, 2, 224, 1, 3>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
     else if (L.kh == 3 && L.kw == 15 && L.cin == 16 && L.cout == 32 && L.sh == 2 && L.sw == 1)    // s_conv2
-      rc = launch_strip_small<16, 3, 2, 15, 1, 144, 2>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      rc = launch_strip_small<16, 3, 2, 15, 1, 144, 2, 2>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
     else
       return 0;
     if (rc) return -rc;
