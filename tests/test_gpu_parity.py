@@ -249,6 +249,17 @@ def test_heads_random_features_many_pairs(engines):
     assert yaw[k.index((4, 4))] == 180
 
 
+def test_heads_signed_and_large_features(engines):
+    """The C ABI takes arbitrary floats, not only ReLU outputs: negative values go through the per-pair shift of the min form
+    (|l - r| = l' + r' - 2 min(l', r'), l' = l - min), large magnitudes through the per-pair power-of-two scales."""
+    rng = np.random.default_rng(23)
+    fv = rng.normal(0.0, 1.0, size=(6, 360, 128)).astype(np.float32)       # signed
+    fv[2] *= 300.0                                                           # one volume 300 x larger than its partners
+    fv[5] = -np.abs(fv[5])                                                   # all negative
+    pairs = np.array([[i, j] for i in range(6) for j in (0, 2, 5)])
+    _check_heads(engines[4], fv, pairs, S.make_test_weights(4, seed=0))
+
+
 def test_one_vs_n_equals_indexed_pairs_and_is_deterministic(engines):
     """1-vs-N sweep (ridx NULL -> query 0, lidx NULL -> identity) == the general indexed form, bit for bit,
     across two runs and across the 2048-pair chunk boundary."""
