@@ -32,7 +32,7 @@
 //                               (global_load_lds_dwordx4): no staging registers, no ds_write pass, no exposed global-load latency
 //   delta_c2_f16x3_kernel       c_conv2 as a streaming GEMM over the (n 576) x 960 matrix of -2 M rows (2.2 MB per pair through HBM)
 // The one-kernel predecessor (o1 image in LDS, c_conv2 as an epilogue phase of every pass: 5.56 ms per 1024 pairs against
-// 4.2 + 0.6 + 0.33 here; its epilogue phase cost 0.93 ms for 0.25 ms of MFMAs, exposed L loads 0.43, W1 register staging 0.35)
+// 4.2 + 0.6 + 0.21 here; its epilogue phase cost 0.93 ms for 0.25 ms of MFMAs, exposed L loads 0.43, W1 register staging 0.35)
 // is kept in tools/experiments/delta_head_f16x3_fused.hip.
 //
 // Scales: weights statically (max |W| -> 2^14), features per PAIR (max over both volumes -> 2^14, so a pair's result does
@@ -279,7 +279,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // scales[2 pair] = {sa, -2 s1r / (sa sw1), s1r, 1 / (s1r sw2)}; s1r = scale of -2 M, bounded by 2 span max_o sum |W1[., o]|.
 // One workgroup per pair and one workgroup per CU (129 KB of LDS), so nothing hides a memory round trip: every phase issues ALL of
 // a thread's loads before it uses the first (the left volume stays in registers from the range scan to the packing; a loop of
-// load / use / load costs one round trip per iteration and made this kernel 0.33 ms per 1024 pairs instead of ~0.15).
+// load / use / load costs one round trip per iteration and made this kernel 0.33 ms per 1024 pairs instead of 0.21).
 __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const float* __restrict__ feats_l, const int32_t* __restrict__ lidx, const float* __restrict__ feats_r,
     const int32_t* __restrict__ ridx, const _Float16* __restrict__ wsp, const float* __restrict__ w1col,
