@@ -230,13 +230,21 @@ class Infer():
     n = len(filenames)
     root = os.path.join(self.datasetpath, self.seq)
     dev = self.engine.device
+    # two sets of pinned staging buffers used alternately: a set is free again once ITS host-to-device copies are done (an event
+    # recorded right behind them), not when the leg that consumes the device copy has finished -- the host never waits for the GPU
     if getattr(self, '_stage', None) is None or self._stage_n < n:
       self._stage_n = max(n, 1)
-      self._stage = {sub: torch.empty((self._stage_n, h, w) + ((k,) if k > 1 else ()), dtype=torch.float32).pin_memory()
-                     for sub, k, _ in self._cue_files()}
+      self._stage = [{sub: torch.empty((self._stage_n, h, w) + ((k,) if k > 1 else ()), dtype=torch.float32).pin_memory()
+                      for sub, k, _ in self._cue_files()} for _ in range(2)]
+      self._stage_free = [None, None]
+      self._stage_next = 0
+    slot = self._stage_next
+    self._stage_next ^= 1
+    if self._stage_free[slot] is not None:
+      self._stage_free[slot].synchronize()
     parts = []
     for sub, k, label in self._cue_files():
-      host = self._stage[sub][:n]
+      host = self._stage[slot][sub][:n]
       hv = host.numpy()
       for i, name in enumerate(filenames):
         f = os.path.join(root, sub, name + '.npy')
@@ -248,6 +256,9 @@ class Infer():
           hv[i] = np.load(os.path.join(root, sub, name + '.npz'))
       d = host.to(dev, non_blocking=True)
       parts.append(d if k > 1 else d.unsqueeze(-1))
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    self._stage_free[slot] = ev
     x = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=-1)
     return x
 
@@ -260,7 +271,6 @@ class Infer():
       k = min(bs, n - s)
       x = self._inputs_device(filenames[s:s + k])
       self.engine.leg(x, out=out[s:s + k])
-      torch.cuda.current_stream(self.engine.device).synchronize()   # the staging buffers are reused by the next batch
     return out
 
   def create_feature_volumes(self, filenames):
