@@ -154,10 +154,12 @@ int ovn_gt_range_images(ovn_ctx* ctx, const float* points_dev, const int64_t* of
 int ovn_gt_overlap_counts(ovn_ctx* ctx, const float* ref_ranges_dev, const float* cur_range_dev, int n_scans, int proj_h,
                           int proj_w, int32_t* counts_dev, void* stream);
 
-/* Arithmetic of the Delta head's c_conv1/c_conv2 contractions (storage and accumulation are fp32 either way):
+/* Arithmetic of the Delta head's contractions (c_conv1, c_conv2, c_conv3) and of ovn_spectrum's DFT; storage and accumulation
+ * are fp32 either way:
  *   0 = fp32 matrix cores (v_mfma_f32_16x16x4_f32; bit-for-bit an fp32 FMA chain),
- *   1 = 3-term bf16 split on the bf16 matrix cores (x = hi + lo, a*w ~ ah*wh + al*wh + ah*wl; ~2^-17 per product)
- *       -- the default; both modes are held to |d overlap| <= 1e-4 against the fp64 oracle by the parity tests. */
+ *   1 = scaled 3-term fp16 split on the fp16 matrix cores (x * 2^k = hi + lo, a*w ~ ah*wh + al*wh + ah*wl; 2^-21 per operand)
+ *       -- the default, measured as accurate as mode 0; both modes are held to |d overlap| <= 1e-4 against the fp64 oracle on
+ *       every pair of the benchmark sweep by the parity tests. */
 int ovn_set_head_precision(ovn_ctx* ctx, int mode);
 
 /* Arithmetic of the leg convolutions, same two modes as ovn_set_head_precision (default 1). */

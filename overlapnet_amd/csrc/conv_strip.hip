@@ -7,7 +7,7 @@
 // pushes it through the slow LDS store path behind a barrier per 32-deep K chunk.  Here a workgroup owns TW output pixels
 // of one output row: the KH input rows it needs ((TW + KW - 1) pixels x CIN channels each) are loaded and split ONCE into
 // an LDS-resident hi/lo strip and every tap is a compile-time address offset into it (the K walk is fully unrolled).
-// Strip layout: one plane per group of 8 channels, [pixel][8 bf16 = 16 B], planes a multiple of 256 B apart: the 16
+// Strip layout: one plane per group of 8 channels, [pixel][8 fp16 = 16 B], planes a multiple of 256 B apart: the 16
 // lanes that ds_read_b128 services together (8 lanes of channel group g, 8 of g+1, consecutive pixels) then cover all 64
 // banks exactly once (a pixel-major layout with any padding gives 2-way conflicts).  No barrier in the K loop (KH x KW x
 // CIN/32 steps of 32 channels, exactly the chunk order of the pre-split weights [kc][nt][hi,lo][lane][8]).  8 waves = NT
@@ -39,7 +39,7 @@ struct StripArgs {
 template <int CIN, int KH, int KW, int TW, int NT>
 struct StripCfg {
   static constexpr int PIX = TW + KW - 1;              // input pixels per strip row
-  static constexpr int PLANE = (KH * PIX * 8 + 127) / 128 * 128;  // bf16 elements per 8-channel plane (multiple of 256 B)
+  static constexpr int PLANE = (KH * PIX * 8 + 127) / 128 * 128;  // fp16 elements per 8-channel plane (multiple of 256 B)
   static constexpr int NPL = CIN / 8;                  // planes
   static constexpr int MT = (TW + 15) / 16;            // m-tiles per workgroup
   static constexpr int MSPLIT = 8 / NT;                // wave groups along M (8 waves = NT n-tiles x MSPLIT)
