@@ -185,6 +185,23 @@ int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3
 /* Device scratch currently held by the context, in bytes (grows on demand, freed by ovn_destroy). */
 int64_t ovn_workspace_bytes(ovn_ctx* ctx);
 
+/* ---- optional collective for consumers that do not use torch.distributed --------------------------
+ * The 1-vs-N sweep shards the candidates over the ranks in contiguous blocks (no data-path collective); its one exchange
+ * step is the gather of the (overlap, yaw) results, 8 bytes per candidate.  RCCL is loaded with dlopen on first use (no
+ * link-time dependency; an RCCL already in the process, e.g. PyTorch's, is reused).  The Python package does not call these
+ * (it goes through torch.distributed, backend "nccl" = RCCL).
+ *   rank 0: ovn_comm_unique_id(id); the application hands the OVN_COMM_ID_BYTES bytes to the other ranks (MPI, file, socket);
+ *   every rank: ovn_comm_init(ctx, rank, world_size, id)  -- collective, one communicator per context, on the context's GPU;
+ *   per query:  ovn_gather_scores(...) -- collective; rank r contributes counts_host[r] candidates (its shard of the sweep, host
+ *               array of world_size entries, identical on every rank); on `root` overlap_all_dev / yaw_all_dev (sum of counts)
+ *               receive the shards in rank order; other ranks may pass NULL result buffers.  Enqueued on `stream`. */
+#define OVN_COMM_ID_BYTES 128
+int ovn_comm_unique_id(unsigned char* id_out);
+int ovn_comm_init(ovn_ctx* ctx, int rank, int world_size, const unsigned char* id);
+int ovn_comm_destroy(ovn_ctx* ctx);
+int ovn_gather_scores(ovn_ctx* ctx, const float* overlap_dev, const int32_t* yaw_dev, const int64_t* counts_host, int root,
+                      float* overlap_all_dev, int32_t* yaw_all_dev, void* stream);
+
 /* Self-test of the MFMA fragment layouts this library relies on (runs a few tiny kernels on the
  * context's device and compares with a host matmul).  0 = all layouts as assumed. */
 int ovn_selftest(ovn_ctx* ctx);

@@ -48,6 +48,10 @@ SIGNATURES = {
     "ovn_debug_conv": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ovn_debug_head_activations": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
     "ovn_workspace_bytes": (C.c_int64, [_vp]),
+    "ovn_comm_unique_id": (C.c_int, [_vp]),
+    "ovn_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "ovn_comm_destroy": (C.c_int, [_vp]),
+    "ovn_gather_scores": (C.c_int, [_vp, _vp, _vp, _i64p, C.c_int, _vp, _vp, _vp]),
     "ovn_selftest": (C.c_int, [_vp]),
 }
 

@@ -85,6 +85,7 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
 
 int ovn_destroy(ovn_ctx* ctx) {
   if (!ctx) return OVN_OK;
+  if (ctx->comm) (void)ovn_comm_destroy(ctx);
   OVN_ON_DEVICE(ctx->device);
   (void)hipDeviceSynchronize();
   for (auto& l : ctx->leg) ovn_conv_release(&l);

@@ -141,6 +141,9 @@ struct ovn_ctx {
   float* bd = nullptr;   // dense bias [1]
   // spectral correlation head: constant twiddle layers (corr_spectral.hip)
   OvnConvLayer dft, idft;
+  // optional RCCL communicator of the sharded sweep (comm.hip)
+  void* comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
   // scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;

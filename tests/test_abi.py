@@ -44,6 +44,11 @@ def test_argument_errors_without_gpu_calls():
     assert lib.ovn_finalize(None, None) == 1
     assert lib.ovn_workspace_bytes(None) == 0
     assert lib.ovn_destroy(None) == 0
+    # the optional collective: argument errors before RCCL is even loaded
+    assert lib.ovn_comm_unique_id(None) == 1 and b"id_out is NULL" in lib.ovn_last_error()
+    assert lib.ovn_comm_init(None, 0, 1, None) == 1
+    assert lib.ovn_comm_destroy(None) == 1
+    assert lib.ovn_gather_scores(None, None, None, None, 0, None, None, None) != 0 and b"no communicator" in lib.ovn_last_error()
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -143,3 +143,35 @@ def test_evaluation_run_on_the_hip_path(tmp_path, fixture_npz):
         assert abs(stats[k] - want[k]) < 1e-4
     assert stats["yaw_mean_err_deg"] == want["yaw_mean_err_deg"] and stats["yaw_max_err_deg"] == want["yaw_max_err_deg"]
     assert stats["yaw_max_err_deg"] == 0              # self pairs -> bin 180 exactly
+
+
+def test_c_abi_collective_one_rank():
+    """ovn_comm_* / ovn_gather_scores (the collective for consumers without torch.distributed) with world_size 1 on the GPU:
+    RCCL is loaded lazily, the gather is a send-to-self inside one group call.  (world_size 2 needs two GPUs; the shard / offset
+    arithmetic it shares with the torch path is covered by the gloo tests.)"""
+    import ctypes as C
+    from overlapnet_amd import _lib
+    from overlapnet_amd.engine import OvnEngine
+    eng = OvnEngine(64, 900, 4)
+    lib, h = eng.lib, eng._h
+    ident = (C.c_ubyte * 128)()
+    _lib.check(lib.ovn_comm_unique_id(ident), "ovn_comm_unique_id")
+    assert any(ident)
+    _lib.check(lib.ovn_comm_init(h, 0, 1, ident), "ovn_comm_init")
+    assert lib.ovn_comm_init(h, 0, 1, ident) != 0            # one communicator per context
+    n = 1000
+    ov = torch.rand(n, device="cuda")
+    yw = torch.randint(-179, 181, (n,), dtype=torch.int32, device="cuda")
+    ov_all = torch.zeros(n, device="cuda")
+    yw_all = torch.zeros(n, dtype=torch.int32, device="cuda")
+    counts = (C.c_int64 * 1)(n)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.ovn_gather_scores(h, ov.data_ptr(), yw.data_ptr(), counts, 0, ov_all.data_ptr(), yw_all.data_ptr(), stream),
+               "ovn_gather_scores")
+    torch.cuda.synchronize()
+    assert torch.equal(ov_all, ov) and torch.equal(yw_all, yw)
+    bad = (C.c_int64 * 1)(-1)
+    assert lib.ovn_gather_scores(h, ov.data_ptr(), yw.data_ptr(), bad, 0, ov_all.data_ptr(), yw_all.data_ptr(), stream) != 0
+    _lib.check(lib.ovn_comm_destroy(h), "ovn_comm_destroy")
+    assert lib.ovn_gather_scores(h, ov.data_ptr(), yw.data_ptr(), counts, 0, ov_all.data_ptr(), yw_all.data_ptr(), stream) != 0
+    eng.close()
