@@ -565,8 +565,7 @@ int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h
   if (ow_out) *ow_out = a.OW;
   if (a.M == 0) return OVN_OK;
   {  // many scans of s_conv3 / s_conv3a: input strip resident in LDS (conv_strip.hip)
-    static const int strip = getenv("OVN_CONV_STRIP") ? atoi(getenv("OVN_CONV_STRIP")) : 1;
-    if (strip && !few_rows) {
+    if (!few_rows) {
       const int took = ovn_conv_strip_try(L, in, nb, call_nb > nb ? call_nb : nb, h, w, out, in_max, out_max, stream);
       if (took < 0) return -took;
       if (took > 0) return OVN_OK;

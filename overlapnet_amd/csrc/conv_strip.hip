@@ -236,7 +236,10 @@ struct SmallCfg {
 // kernels that is not hidden: 52 MFMAs per wave against a 38 KB strip at ROWS = 1) is KH + SH (ROWS - 1) rows instead of KH ROWS.
 // s_conv1: 3 rows per block (9 strip rows for 15), s_conv2: 2 (5 for 6): batched leg 6.50 -> 6.05 ms per 1025 scans, almost all
 // of it from s_conv2; same K order per accumulator as ROWS = 1, bit-identical results.
-template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS>
+// OWN: the input scale comes from the strip's own largest |value| (all of the strip is in registers before it is split anyway)
+// instead of the call-wide maximum in *a.in_max -- the first layer then needs no absmax pass over the images (0.33 ms per 1025
+// scans), and a scan's result does not depend on the other scans of the call.
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS, bool OWN>
 __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   typedef SmallCfg<CIN, KH, SH, KW, SW, TW, NT, ROWS> C;
   constexpr int COUT = 16 * NT;
@@ -244,8 +247,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
   _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
   _Float16* sl = sh + KHS * PIXA * CIN;
-  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
-  const float inv = 1.0f / (s_in * a.sw);
+  float s_in = OWN ? 1.0f : ovn_pow2_scale_for(__uint_as_float(*a.in_max));
   const float one = a.one;
 
   const int tid = threadIdx.x;
@@ -272,7 +274,8 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
     constexpr int Q = CIN / 4;
     constexpr int TOTAL = KHS * PIXA * Q;
     constexpr int ITERS = (TOTAL + 511) / 512;
-    constexpr int BATCH = 4;
+    constexpr int BATCH = OWN ? ITERS : 4;   // OWN: the whole strip in one batch (its maximum is needed before the first split)
+    static_assert(!OWN || ITERS <= 12, "strip too large to hold in registers");
 #pragma unroll 1
     for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
       f32x4 v[BATCH];
@@ -288,6 +291,21 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
           if (pix < pixv && SH * oy + row < a.H)   // rows past the image belong to output rows past OH (odd row counts)
             v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + px0 + pix) * CIN + c);
         }
+      }
+      if (OWN) {   // workgroup maximum through the (not yet written) start of the lo image
+        float m = 0.f;
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][0]), fabsf(v[u][1])), fmaxf(fabsf(v[u][2]), fabsf(v[u][3]))));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_down(m, off, 64));
+        float* red = reinterpret_cast<float*>(sl);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        m = red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w]);
+        __syncthreads();   // everyone has read the scratch before the lo image overwrites it
+        s_in = ovn_pow2_scale_for(m);
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
@@ -309,6 +327,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
       }
     }
   }
+  const float inv = 1.0f / (s_in * a.sw);
 
   // per-lane fragment base: output pixel lrow of the wave's first m-tile, k offset of lane group g
   const int goff = ((8 * g) / CIN) * CIN + (8 * g) % CIN;       // = 8 g: pixel-major makes (pixel, channel) linear
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   }
 }
 
-template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS>
+template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS, bool OWN>
 int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out, const unsigned* in_max,
                        unsigned* out_max, hipStream_t stream, bool* took) {
   typedef SmallCfg<CIN, KH, SH, KW, SW, TW, NT, ROWS> C;
@@ -393,9 +412,9 @@ int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long
   const long long wgs = (long long)nb * ((a.OH + ROWS - 1) / ROWS) * a.XT;
   *took = call_nb * a.OH * a.XT >= 384;
   if (!*took) return OVN_OK;
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS>), C::LDS_BYTES);
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS, OWN>), C::LDS_BYTES);
   if (rc) return rc;
-  hipLaunchKernelGGL((conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS, OWN>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -434,6 +453,15 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_
 
 static int pad_rows(int ow, int tw) { return (ow + tw - 1) / tw * tw - ow; }   // padded output pixels per row with tiles of tw
 
+// True when ovn_conv_strip_try will run this layer with a kernel that scales its input by the strip's own maximum (s_conv1 at
+// C = 4 in batched calls): the caller then skips the absmax pass over the layer's input.
+bool ovn_conv_strip_own_scale(const OvnConvLayer& L, long long call_nb, int h, int w) {
+  if (!(L.relu && L.wp_h != nullptr && L.wp_h16 != nullptr) || h < L.kh || w < L.kw) return false;
+  if (!(L.kh == 5 && L.kw == 15 && L.cin == 4 && L.cout == 16 && L.sh == 2 && L.sw == 2)) return false;
+  const int oh = (h - 5) / 2 + 1, ow = (w - 15) / 2 + 1;
+  return call_nb * oh * ((ow + 223) / 224) >= 384;
+}
+
 // Returns 1 when the layer / call was taken (result in out), 0 when the caller should use the generic kernel, < 0 on error.
 int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out,
                        const unsigned* in_max, unsigned* out_max, hipStream_t stream) {
@@ -443,9 +471,9 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
   int rc = OVN_OK;
   if (L.wp_h16 != nullptr) {   // few input channels: pixel-major strips, taps padded to 16
     if (L.kh == 5 && L.kw == 15 && L.cin == 4 && L.cout == 16 && L.sh == 2 && L.sw == 2)          // s_conv1 at C = 4
-      rc = launch_strip_small<4, 5, 2, 15, 2, 224, 1, 3>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      rc = launch_strip_small<4, 5, 2, 15, 2, 224, 1, 3, true>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
     else if (L.kh == 3 && L.kw == 15 && L.cin == 16 && L.cout == 32 && L.sh == 2 && L.sw == 1)    // s_conv2
-      rc = launch_strip_small<16, 3, 2, 15, 1, 144, 2, 2>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      rc = launch_strip_small<16, 3, 2, 15, 1, 144, 2, 2, false>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
     else
       return 0;
     if (rc) return -rc;

@@ -254,9 +254,13 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
     int h = ctx->in_h, w = ctx->in_w;
     if (ctx->leg_mode != 0) {   // f16x3: slot li = max |input of layer li| of this slice, folded by the producing kernel
       OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, OVN_ACTMAX_SLOTS * sizeof(unsigned), stream));
-      OvnProfScope ps(ctx, OVN_K_LEG, stream);
-      rc = ovn_absmax_forward(cur, (long long)nb * (long long)in_elems, ctx->actmax, stream);
-      if (rc) return rc;
+      // (skipped when the first layer's kernel takes the maximum of each input strip itself)
+      const bool own = n > 8 && (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_conv_strip_own_scale(ctx->leg[0], n, h, w);
+      if (!own) {
+        OvnProfScope ps(ctx, OVN_K_LEG, stream);
+        rc = ovn_absmax_forward(cur, (long long)nb * (long long)in_elems, ctx->actmax, stream);
+        if (rc) return rc;
+      }
     }
     for (size_t li = 0; li < ctx->leg.size(); ++li) {
       const bool last = (li + 1 == ctx->leg.size());

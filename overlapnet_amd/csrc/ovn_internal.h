@@ -228,6 +228,7 @@ int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream);
 int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra, hipStream_t stream);
 // conv_strip.hip: LDS-resident strip kernels for the 3 x KW / stride (2,1) leg layers with 64 outputs (f16x3 mode)
 // call_nb: scans of the whole call this slice belongs to (kernel choice is per call, not per slice)
+bool ovn_conv_strip_own_scale(const OvnConvLayer& L, long long call_nb, int h, int w);
 int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out,
                        const unsigned* in_max, unsigned* out_max, hipStream_t stream);
 
