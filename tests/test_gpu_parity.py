@@ -541,6 +541,45 @@ def test_infer_with_intensity_channel_and_missing_files(tmp_path, fixture_npz):
         Infer(cfg3, weights=w)
 
 
+def test_yaw_argmax_on_16384_seeded_pairs(engines):
+    """Exact yaw bin on 16384 seeded pairs (>= 1e4), both forms of the correlation head, against the fp64
+    correlation evaluated per channel with numpy's FFT -- the same sum as the oracle's wrapped Gram diagonals, checked against
+    `O.correlation_head_forward` on a sample -- with the contract's near-tie rule (top-2 gap below 1e-5 relative may differ)."""
+    n, npool = 16384, 512
+    rng = np.random.default_rng(2024)
+    pool = np.maximum(rng.normal(0.15, 1.0, size=(npool, 360, 128)), 0).astype(np.float32)
+    pool[7] = np.roll(pool[3], 111, axis=0)
+    li = rng.integers(0, npool, size=n)
+    ri = rng.integers(0, npool, size=n)
+    F = np.fft.rfft(pool.astype(np.float64), axis=1)                          # (npool, 181, 128)
+
+    def corr64(a, b):    # corr[k] = sum_{j,c} l[(k + j + 180) mod 360, c] r[j, c]
+        c = np.fft.irfft((F[a] * np.conj(F[b])).sum(axis=2), n=360, axis=1)
+        return np.roll(c, -180, axis=1)
+
+    sample = np.arange(0, n, n // 6)
+    lit = O.correlation_head_forward(pool[li[sample]][:, None].astype(np.float64), pool[ri[sample]][:, None].astype(np.float64))
+    assert np.max(np.abs(corr64(li[sample], ri[sample]) - lit)) <= 1e-9 * np.max(np.abs(lit))
+    e = engines[4]
+    pt = torch.from_numpy(pool).cuda()
+    spec = e.spectrum(pt)
+    g_spec = e.corr_head_spectral(spec, spec, lidx=li, ridx=ri)["yaw"].cpu().numpy()
+    g_dir = e.corr_head(pt, pt, lidx=li, ridx=ri)["yaw"].cpu().numpy()
+    nbad = {"spectral": 0, "direct": 0}
+    for s0 in range(0, n, 2048):
+        sl = slice(s0, s0 + 2048)
+        c = corr64(li[sl], ri[sl])
+        yaw = 180 - np.argmax(c, axis=1)
+        srt = np.sort(c, axis=1)
+        gap = (srt[:, -1] - srt[:, -2]) / np.abs(srt[:, -1])
+        for name, g in (("spectral", g_spec[sl]), ("direct", g_dir[sl])):
+            bad = g != yaw
+            nbad[name] += int(bad.sum())
+            assert not np.any(bad & (gap > 1e-5)), (name, g[bad], yaw[bad], gap[bad])
+    print("yaw over %d pairs: %s bins differ from the fp64 argmax, all with a top-2 gap <= 1e-5" % (n, nbad))
+    assert nbad["spectral"] <= 16 and nbad["direct"] <= 16
+
+
 def test_full_size_sweep_properties(engines):
     """BASELINE-sized 1-vs-1024 sweep, size-independent properties: candidate k = query rolled by k columns must
     come back with yaw bin 180 + k (mod 360) -> yaw = -k wrapped, and rolling leaves the overlap logit of the
