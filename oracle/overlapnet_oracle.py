@@ -236,7 +236,8 @@ def delta_head_forward(feat_l: np.ndarray, feat_r: np.ndarray, weights: Dict[str
         if return_intermediates and b == n - 1:
             inter = {"o1": o1[0].permute(1, 2, 0).numpy(), "o2": o2[0].permute(1, 2, 0).numpy(),
                      "o3": o3[0].permute(1, 2, 0).numpy()}
-    overlap = 1.0 / (1.0 + np.exp(-logits.astype(F64)))
+    with np.errstate(over="ignore"):   # exp(+large) = inf -> sigmoid 0, as Keras' sigmoid saturates
+        overlap = 1.0 / (1.0 + np.exp(-logits.astype(F64)))
     overlap = overlap.astype(dtype)
     if return_intermediates:
         return overlap, logits, inter
