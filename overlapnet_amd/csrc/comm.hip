@@ -58,7 +58,11 @@ void load_rccl() {
 
 int need_rccl() {
   std::call_once(g_rccl_once, load_rccl);
-  OVN_REQUIRE(g_rccl.ok, OVN_ERR_STATE, "RCCL (librccl.so.1) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  if (!g_rccl.ok) {
+    const char* why = dlerror();   // (dlerror clears its message when read)
+    ovn_set_error("RCCL (librccl.so.1) could not be loaded: %s", why ? why : "a required ncclXxx symbol is missing");
+    return OVN_ERR_STATE;
+  }
   return OVN_OK;
 }
 
