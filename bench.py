@@ -23,6 +23,7 @@ contiguous blocks over the ranks (overlapnet_amd.distributed.shard_bounds), feat
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -123,6 +124,22 @@ def cpu_baseline(channels: int, pool: int):
                       "1 leg + %d pairs; leg %.3f s/scan, heads %.4f s/pair" % (pool, t_leg, t_pair)}
 
 
+def relaunch_command(argv, gpus, port=None, python=None):
+    """The command line `python bench.py --gpus N ...` re-executes itself with when it was started without a launcher:
+    the one the driver uses for N > 1 (one rank per GPU of ONE node, rendezvous on 127.0.0.1)."""
+    if port is None:
+        port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def relaunch_env(env):
+    e = dict(env)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL across processes)
+    e.setdefault("OMP_NUM_THREADS", "8")
+    return e
+
+
 def timed(step, warmup, steps, eng, use_dist, dev):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks.
     Returns (elapsed_s, per-kernel HIP-event profile, last step result)."""
@@ -199,11 +216,17 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, rank 0 prints the
+        # ONE JSON line on the inherited stdout (one process per GPU, RCCL over xGMI)
+        cmd = relaunch_command(sys.argv[1:], args.gpus)
+        raise SystemExit(subprocess.call(cmd, env=relaunch_env(os.environ)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    visible = torch.cuda.device_count()
+    if visible < max(world, 1) or local_rank >= visible:
+        raise SystemExit("bench.py: %d GPUs needed, %d visible (rank %d)" % (world, visible, rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist

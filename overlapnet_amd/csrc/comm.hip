@@ -6,6 +6,7 @@
 // RCCL (PyTorch ships its own) keeps using that one.  One send + one receive list inside a single group call: every rank sends
 // its two arrays to `root`, the root posts world x 2 receives straight into the result arrays at the shard offsets.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <string.h>
 #include <rccl/rccl.h>
 
@@ -29,6 +30,7 @@ struct RcclApi {
 
 RcclApi g_rccl;
 std::once_flag g_rccl_once;
+char g_rccl_why[512] = "";   // why loading failed, captured ONCE inside load_rccl (dlerror clears its message when read)
 
 void load_rccl() {
   void* h = nullptr;
@@ -42,7 +44,11 @@ void load_rccl() {
       h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
       if (h) break;
     }
-  if (!h) return;
+  if (!h) {
+    const char* why = dlerror();
+    snprintf(g_rccl_why, sizeof(g_rccl_why), "%s", why ? why : "dlopen failed");
+    return;
+  }
   RcclApi a;
   a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
   a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
@@ -53,14 +59,14 @@ void load_rccl() {
   a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
   a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
   a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.GetErrorString;
+  if (!a.ok) snprintf(g_rccl_why, sizeof(g_rccl_why), "a required ncclXxx symbol is missing");
   g_rccl = a;
 }
 
 int need_rccl() {
   std::call_once(g_rccl_once, load_rccl);
   if (!g_rccl.ok) {
-    const char* why = dlerror();   // (dlerror clears its message when read)
-    ovn_set_error("RCCL (librccl.so.1) could not be loaded: %s", why ? why : "a required ncclXxx symbol is missing");
+    ovn_set_error("RCCL (librccl.so.1) could not be loaded: %s", g_rccl_why);
     return OVN_ERR_STATE;
   }
   return OVN_OK;
@@ -70,6 +76,18 @@ int need_rccl() {
   do {                                                                                              \
     ncclResult_t _r = (expr);                                                                       \
     if (_r != ncclSuccess) {                                                                        \
+      ovn_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
+      return OVN_ERR_HIP;                                                                           \
+    }                                                                                               \
+  } while (0)
+
+// inside a ncclGroupStart/ncclGroupEnd bracket: close the group (ignoring its result) before reporting the error, so that the
+// thread is not left inside an open group in which every later collective would hang
+#define OVN_RCCL_CHECK_IN_GROUP(expr)                                                               \
+  do {                                                                                              \
+    ncclResult_t _r = (expr);                                                                       \
+    if (_r != ncclSuccess) {                                                                        \
+      (void)g_rccl.GroupEnd();                                                                      \
       ovn_set_error("%s failed: %s (%s:%d)", #expr, g_rccl.GetErrorString(_r), __FILE__, __LINE__); \
       return OVN_ERR_HIP;                                                                           \
     }                                                                                               \
@@ -137,15 +155,15 @@ int ovn_gather_scores(ovn_ctx* ctx, const float* overlap_dev, const int32_t* yaw
   ncclComm_t comm = static_cast<ncclComm_t>(ctx->comm);
   OVN_RCCL_CHECK(g_rccl.GroupStart());
   if (mine > 0) {
-    OVN_RCCL_CHECK(g_rccl.Send(overlap_dev, (size_t)mine, ncclFloat32, root, comm, stream));
-    OVN_RCCL_CHECK(g_rccl.Send(yaw_dev, (size_t)mine, ncclInt32, root, comm, stream));
+    OVN_RCCL_CHECK_IN_GROUP(g_rccl.Send(overlap_dev, (size_t)mine, ncclFloat32, root, comm, stream));
+    OVN_RCCL_CHECK_IN_GROUP(g_rccl.Send(yaw_dev, (size_t)mine, ncclInt32, root, comm, stream));
   }
   if (ctx->comm_rank == root) {
     int64_t off = 0;
     for (int r = 0; r < ctx->comm_world; ++r) {
       if (counts_host[r] > 0) {
-        OVN_RCCL_CHECK(g_rccl.Recv(overlap_all_dev + off, (size_t)counts_host[r], ncclFloat32, r, comm, stream));
-        OVN_RCCL_CHECK(g_rccl.Recv(yaw_all_dev + off, (size_t)counts_host[r], ncclInt32, r, comm, stream));
+        OVN_RCCL_CHECK_IN_GROUP(g_rccl.Recv(overlap_all_dev + off, (size_t)counts_host[r], ncclFloat32, r, comm, stream));
+        OVN_RCCL_CHECK_IN_GROUP(g_rccl.Recv(yaw_all_dev + off, (size_t)counts_host[r], ncclInt32, r, comm, stream));
       }
       off += counts_host[r];
     }

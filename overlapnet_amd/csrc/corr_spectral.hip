@@ -14,10 +14,9 @@
 //   * ovn_spectrum:  the DFT is a dense contraction with a constant 360 x 368 twiddle matrix: dft_f16x3_kernel (scaled fp16
 //     hi/lo split on the fp16 matrix cores, default) or, in the fp32 head mode, the generic fp32 conv kernel (a 360x1 'valid'
 //     convolution over the (360,128) feature image).
-//   * spectral_product_kernel: one workgroup per pair, thread = (4 consecutive frequencies, 32 channels); partial
-//     sums of the 4 channel groups are combined in LDS in a fixed order (deterministic).
-//   * the inverse transform of the 368-vector C^ is again a constant contraction (1x1 conv, 368 -> 368) and the
-//     argmax (first maximum wins) is a fixed-order wave reduction.
+//   * spectral_corr_kernel: ONE launch per sweep, one workgroup per pair: spectral product (the candidate spectrum streamed once),
+//     inverse transform of the 181 Hermitian coefficients shifted by W/2 in fp64 registers, first-maximum argmax -- nothing but
+//     yaw (and, on request, the 360 correlation values) leaves the kernel.
 #include <math.h>
 
 #include <vector>
@@ -36,17 +35,54 @@ constexpr int CG = 4;              // channel groups of 32
 constexpr int PROD_THREADS = 192;  // 184 working threads
 constexpr int SWP = 384;           // SW padded with zero filters to 3 x 128 so the conv kernel can use its 64 x 128 tile
 
-// C^ for one pair: out[pair][f] = Re, out[pair][184 + f] = Im, padding zero.
-__global__ __launch_bounds__(PROD_THREADS) void spectral_product_kernel(const float* __restrict__ spec_l,
-                                                                       const int32_t* __restrict__ lidx,
-                                                                       const float* __restrict__ spec_r,
-                                                                       const int32_t* __restrict__ ridx,
-                                                                       float* __restrict__ chat) {
+// Yaw head of one pair in ONE launch: spectral product -> Hermitian inverse transform shifted by W/2 (RangePadding2D) -> first
+// maximum (infer.py:158).  One workgroup per pair.
+//   phase 1 (HBM-bound): thread = (4 consecutive frequencies, 32 channels); the candidate spectrum is streamed once (188,416 B), the
+//     query spectrum comes from L2; partial sums of the 4 channel groups are combined in LDS in a fixed order.
+//   phase 2: corr[k] = sum_f wf/360 (Re C^[f] cos(2 pi f (k+180)/360) - Im C^[f] sin(2 pi f (k+180)/360)), wf = 1 for f = 0, 180, else 2.
+//     With a_f = (-1)^f wf/360 Re C^[f], b_f = (-1)^f wf/360 Im C^[f] (the shift by 180 bins is the sign (-1)^f) and
+//     E = sum_f a_f cos(f x), O = sum_f b_f sin(f x), x = 2 pi k / 360, split by the parity of f (Ee, Eo, Oe, Oo):
+//         corr[k] = (Ee + Eo) - (Oe + Oo)      corr[360 - k] = (Ee + Eo) + (Oe + Oo)
+//         corr[180 - k] = (Ee - Eo) + (Oe - Oo)      corr[180 + k] = (Ee - Eo) - (Oe - Oo)
+//     so k = 0..90 gives all 360 bins.  Thread (k, half h) walks 90 / 92 frequencies with the Chebyshev recurrence
+//     cos((f+1)x) = 2 cos x cos(fx) - cos((f-1)x) (same for sin) in FP64, started from an exact fp64 table: four DFMAs per (k, f),
+//     no table lookups in the loop, no LDS bank conflicts, and the sums are exact to fp64 rounding (the fp32 contraction this
+//     replaces carried 181 fp32 roundings per bin).  The two halves are added in a fixed order.
+//   phase 3: first maximum over the 360 bins (lowest index wins ties) by a fixed-order wave + LDS reduction; yaw = 180 - argmax.
+constexpr int KH = 96;             // threads per frequency half in phase 2 (k = 0..90 active)
+constexpr int NK = FW / 4 + 1;     // 91 values of k
+constexpr int F_SPLIT = 90;        // half 0: f = 0..89, half 1: f = 90..180 (+ the zero pad 181)
+
+__global__ __launch_bounds__(PROD_THREADS) void spectral_corr_kernel(const float* __restrict__ spec_l,
+                                                                    const int32_t* __restrict__ lidx,
+                                                                    const float* __restrict__ spec_r,
+                                                                    const int32_t* __restrict__ ridx,
+                                                                    const double* __restrict__ tw64,   // [2][360]: cos, sin(2 pi m / 360)
+                                                                    int32_t* __restrict__ yaw, float* __restrict__ corr_out) {
   __shared__ float part[CG][2][IM_OFF];
+  __shared__ __attribute__((aligned(16))) double ab[NF + 1][2];
+  __shared__ double half1[NK][4];
+  __shared__ float rv[3];
+  __shared__ int ri[3];
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const float* L = spec_l + (long long)(lidx ? lidx[pair] : pair) * OVN_SPEC_ELEMS;
   const float* R = spec_r + (long long)(ridx ? ridx[pair] : 0) * OVN_SPEC_ELEMS;
+  // table entries of this thread's recurrence start: issued before the streaming loop, used after it
+  const int k = tid < KH ? tid : tid - KH;
+  const int half = tid < KH ? 0 : 1;
+  const bool idft_thread = k < NK;
+  const int f0 = half ? F_SPLIT : 0;
+  double c0 = 0.0, cm = 0.0, s0 = 0.0, sm = 0.0, twoc = 0.0;
+  if (idft_thread) {
+    const int m0 = (f0 * k) % FW;                    // angle index of f0
+    const int m1 = (m0 + FW - k) % FW;               // ... of f0 - 1
+    c0 = tw64[m0];
+    s0 = tw64[FW + m0];
+    cm = tw64[m1];
+    sm = tw64[FW + m1];
+    twoc = 2.0 * tw64[k];
+  }
   if (tid < FQ * CG) {
     const int fq = tid % FQ;
     const int cg = tid / FQ;
@@ -55,8 +91,8 @@ __global__ __launch_bounds__(PROD_THREADS) void spectral_product_kernel(const fl
     const float* rrow = R + (cg * 32) * SW + 4 * fq;
 #pragma unroll 8
     for (int c = 0; c < 32; ++c) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(lrow + c * SW);            // Re L^
-      const f32x4 b = *reinterpret_cast<const f32x4*>(lrow + c * SW + IM_OFF);   // Im L^
+      const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(lrow + c * SW));            // Re L^ (read once)
+      const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(lrow + c * SW + IM_OFF));   // Im L^
       const f32x4 p = *reinterpret_cast<const f32x4*>(rrow + c * SW);            // Re R^
       const f32x4 q = *reinterpret_cast<const f32x4*>(rrow + c * SW + IM_OFF);   // Im R^
       sre += a * p + b * q;   // (a + ib)(p - iq)
@@ -69,34 +105,71 @@ __global__ __launch_bounds__(PROD_THREADS) void spectral_product_kernel(const fl
     }
   }
   __syncthreads();
-  if (tid < IM_OFF) {
-    float re = 0.f, im = 0.f;
+  if (tid < NF + 1) {
+    double a = 0.0, b = 0.0;
     if (tid < NF) {
-      re = (part[0][0][tid] + part[1][0][tid]) + (part[2][0][tid] + part[3][0][tid]);
-      im = (part[0][1][tid] + part[1][1][tid]) + (part[2][1][tid] + part[3][1][tid]);
+      const float re = (part[0][0][tid] + part[1][0][tid]) + (part[2][0][tid] + part[3][0][tid]);
+      const float im = (part[0][1][tid] + part[1][1][tid]) + (part[2][1][tid] + part[3][1][tid]);
+      const double wf = ((tid == 0 || tid == FW / 2) ? 1.0 : 2.0) / (double)FW * ((tid & 1) ? -1.0 : 1.0);
+      a = wf * (double)re;
+      b = wf * (double)im;
     }
-    chat[(long long)pair * SW + tid] = re;
-    chat[(long long)pair * SW + IM_OFF + tid] = im;
+    ab[tid][0] = a;   // entry 181 is a zero pad: both halves walk an even number of frequencies
+    ab[tid][1] = b;
   }
-}
-
-// yaw = 180 - argmax (first maximum wins) over corr[pair][0..359]; optionally copies the 360 values out.
-__global__ __launch_bounds__(256) void corr_argmax_kernel(const float* __restrict__ corr368, int32_t* __restrict__ yaw,
-                                                          float* __restrict__ corr_out) {
-  __shared__ float rv[4];
-  __shared__ int ri[4];
-  const int pair = blockIdx.x;
-  const int tid = threadIdx.x;
-  const float* c = corr368 + (long long)pair * SW;
+  __syncthreads();
+  // phase 2: both halves start on an even frequency and walk whole (even, odd) pairs: half 0 f = 0..89, half 1 f = 90..181 (181 = pad)
+  double ee = 0.0, eo = 0.0, oe = 0.0, oo = 0.0;
+  if (idft_thread) {
+    const int npairs = half ? (NF + 1 - F_SPLIT) / 2 : F_SPLIT / 2;   // 46 : 45
+    double cc = c0, cp = cm, sc = s0, sp = sm;                         // cos / sin of f x and of (f - 1) x
+    for (int j = 0; j < npairs; ++j) {
+      const int f = f0 + 2 * j;
+      const double a0 = ab[f][0], b0 = ab[f][1], a1 = ab[f + 1][0], b1 = ab[f + 1][1];
+      const double cn = __builtin_fma(twoc, cc, -cp), sn = __builtin_fma(twoc, sc, -sp);     // (f + 1) x
+      ee = __builtin_fma(a0, cc, ee);
+      oe = __builtin_fma(b0, sc, oe);
+      eo = __builtin_fma(a1, cn, eo);
+      oo = __builtin_fma(b1, sn, oo);
+      cp = cn;
+      sp = sn;
+      cc = __builtin_fma(twoc, cn, -cc);                                                      // (f + 2) x
+      sc = __builtin_fma(twoc, sn, -sc);
+    }
+    if (half) {
+      half1[k][0] = ee;
+      half1[k][1] = eo;
+      half1[k][2] = oe;
+      half1[k][3] = oo;
+    }
+  }
+  __syncthreads();
   float bv = -INFINITY;
   int bi = 0x7fffffff;
-  for (int k = tid; k < FW; k += 256) {
-    const float v = c[k];
-    if (corr_out) corr_out[(long long)pair * FW + k] = v;
-    if (v > bv || (v == bv && k < bi)) {
-      bv = v;
-      bi = k;
-    }
+  if (!half && idft_thread) {
+    ee += half1[k][0];
+    eo += half1[k][1];
+    oe += half1[k][2];
+    oo += half1[k][3];
+    const double es = ee + eo, ed = ee - eo, os = oe + oo, od = oe - oo;
+    // bins k, 360 - k, 180 - k, 180 + k (each bin exactly once over k = 0..90), in increasing index order per candidate list
+    const float v0 = (float)(es - os), v1 = (float)(es + os), v2 = (float)(ed + od), v3 = (float)(ed - od);
+    const int i0 = k, i1 = FW - k, i2 = FW / 2 - k, i3 = FW / 2 + k;
+    const bool u0 = true, u1 = (k >= 1), u2 = (k <= NK - 2), u3 = (k >= 1 && k <= NK - 2);
+    float* co = corr_out ? corr_out + (long long)pair * FW : nullptr;
+#define OVN_TAKE(U, V, I)                                   \
+  if (U) {                                                  \
+    if (co) co[I] = V;                                      \
+    if (V > bv || (V == bv && I < bi)) {                    \
+      bv = V;                                               \
+      bi = I;                                               \
+    }                                                       \
+  }
+    OVN_TAKE(u0, v0, i0)
+    OVN_TAKE(u1, v1, i1)
+    OVN_TAKE(u2, v2, i2)
+    OVN_TAKE(u3, v3, i3)
+#undef OVN_TAKE
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
@@ -115,15 +188,14 @@ __global__ __launch_bounds__(256) void corr_argmax_kernel(const float* __restric
   if (tid == 0) {
     float v = rv[0];
     int i = ri[0];
-    for (int w = 1; w < 4; ++w)
+    for (int w = 1; w < 2; ++w)   // bins live in threads 0..90: waves 0 and 1
       if (rv[w] > v || (rv[w] == v && ri[w] < i)) {
         v = rv[w];
         i = ri[w];
       }
-    yaw[pair] = FW / 2 - i;
+    yaw[pair] = FW / 2 - (i == 0x7fffffff ? 0 : i);   // every bin NaN: bin 0, like np.argmax's first NaN
   }
 }
-
 
 // ---- forward DFT on the fp16 matrix cores (f16x3 arithmetic, see delta_head_f16x3.hip) -------------------------------------------
 // spectra[scan][c][col] = sum_i X[scan][i][c] T[i][col]: per scan a (128 x 360) x (360 x 368) product whose A operand is the
@@ -306,29 +378,21 @@ int ovn_spectral_prepare(ovn_ctx* ctx, hipStream_t stream) {
     int rc = upload_layer(&L, w, stream, true);
     if (rc) return rc;
   }
-  {  // inverse transform of the Hermitian half, shifted by W/2 (RangePadding2D), as a (1,1,368,368) convolution
-    OvnConvLayer& L = ctx->idft;
-    L = OvnConvLayer();
-    L.name = "idft360";
-    L.kh = 1;
-    L.kw = 1;
-    L.cin = SW;
-    L.cout = SWP;
-    L.out_cols = SW;
-    L.sh = 1;
-    L.sw = 1;
-    L.relu = 0;
-    std::vector<float> w((size_t)SW * SWP, 0.f);
-    for (int f = 0; f < NF; ++f) {
-      const double wf = ((f == 0 || f == FW / 2) ? 1.0 : 2.0) / FW;
-      for (int k = 0; k < FW; ++k) {
-        const double ang = w0 * (double)((long long)f * (k + FW / 2) % FW);
-        w[(size_t)f * SWP + k] = (float)(wf * cos(ang));
-        w[(size_t)(IM_OFF + f) * SWP + k] = (float)(-wf * sin(ang));
-      }
+  {  // exact fp64 table cos / sin (2 pi m / 360), m = 0..359: start values of the inverse transform's recurrences (spectral_corr_kernel)
+    std::vector<double> t(2 * FW);
+    for (int m = 0; m < FW; ++m) {
+      // octant reduction so that the table is exactly symmetric (cos 90 deg = 0, sin 180 deg = 0, ...)
+      const int q = m / 90, r = m % 90;
+      const double ang = w0 * (double)r;
+      const double c = (r == 0) ? 1.0 : cos(ang), sn = (r == 0) ? 0.0 : sin(ang);
+      const double cs[4] = {c, -sn, -c, sn}, ss[4] = {sn, c, -sn, -c};
+      t[m] = cs[q];
+      t[FW + m] = ss[q];
     }
-    int rc = upload_layer(&L, w, stream);
-    if (rc) return rc;
+    if (ctx->tw64) (void)hipFree(ctx->tw64);
+    ctx->tw64 = nullptr;
+    OVN_HIP_CHECK(hipMalloc((void**)&ctx->tw64, t.size() * sizeof(double)));
+    OVN_HIP_CHECK(hipMemcpy(ctx->tw64, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
   }
   return OVN_OK;
 }
@@ -355,17 +419,7 @@ int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra
 
 int ovn_corr_spectral_forward(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,
                               const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream) {
-  const size_t vec_bytes = ((size_t)n * SW * sizeof(float) + 255) & ~(size_t)255;
-  int rc = ovn_ws_reserve(ctx, 2 * vec_bytes, stream);
-  if (rc) return rc;
-  float* chat = reinterpret_cast<float*>(ctx->ws);
-  float* c368 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + vec_bytes);
-  hipLaunchKernelGGL(spectral_product_kernel, dim3(n), dim3(PROD_THREADS), 0, stream, spec_l, lidx, spec_r, ridx, chat);
-  OVN_HIP_CHECK(hipGetLastError());
-  int oh = 0, ow = 0;
-  rc = ovn_conv_forward(ctx->idft, chat, n, 1, 1, c368, &oh, &ow, stream);
-  if (rc) return rc;
-  hipLaunchKernelGGL(corr_argmax_kernel, dim3(n), dim3(256), 0, stream, c368, yaw, corr);
+  hipLaunchKernelGGL(spectral_corr_kernel, dim3(n), dim3(PROD_THREADS), 0, stream, spec_l, lidx, spec_r, ridx, ctx->tw64, yaw, corr);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

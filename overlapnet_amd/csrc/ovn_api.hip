@@ -75,7 +75,7 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
   int rc = ovn_spectral_prepare(c, nullptr);
   if (rc) {
     ovn_conv_release(&c->dft);
-    ovn_conv_release(&c->idft);
+    if (c->tw64) (void)hipFree(c->tw64);
     delete c;
     return rc;
   }
@@ -92,7 +92,7 @@ int ovn_destroy(ovn_ctx* ctx) {
   ovn_conv_release(&ctx->c2);
   ovn_conv_release(&ctx->c3);
   ovn_conv_release(&ctx->dft);
-  ovn_conv_release(&ctx->idft);
+  if (ctx->tw64) (void)hipFree(ctx->tw64);
   if (ctx->w1p) (void)hipFree(ctx->w1p);
   if (ctx->b1) (void)hipFree(ctx->b1);
   if (ctx->wd) (void)hipFree(ctx->wd);

@@ -140,7 +140,8 @@ struct ovn_ctx {
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
   // spectral correlation head: constant twiddle layers (corr_spectral.hip)
-  OvnConvLayer dft, idft;
+  OvnConvLayer dft;        // forward transform as a conv layer (fp32 mode) + its fp16 hi/lo fragments (dft_f16x3_kernel)
+  double* tw64 = nullptr;  // [2][360] cos / sin (2 pi m / 360) in fp64: start values of the inverse transform (spectral_corr_kernel)
   // optional RCCL communicator of the sharded sweep (comm.hip)
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;

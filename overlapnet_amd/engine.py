@@ -46,6 +46,7 @@ class OvnEngine:
         self._head_ready = False
         self.head_precision = "f16x3"
         self.leg_precision = "f16x3"
+        self.check_device_indices = False    # opt-in range check of pair-index tensors that already live on the device (_idx)
 
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:
@@ -115,10 +116,18 @@ class OvnEngine:
 
     def _idx(self, idx, n: Optional[int], bound: Optional[int] = None, what: str = "pair index") -> Optional[torch.Tensor]:
         """Index list -> int32 device tensor.  Host lists / arrays are range-checked ON THE HOST before the upload (no device
-        synchronisation); a tensor that already lives on the device is trusted as is (the caller built it)."""
+        synchronisation).  A tensor that already lives on the device is TRUSTED (the caller built it; the kernels read
+        feats[idx[p]] without a bound check, an out-of-range entry reads foreign memory) unless `self.check_device_indices` is set,
+        which range-checks it on the device at the price of one synchronisation per call."""
         if idx is None:
             return None
         if isinstance(idx, torch.Tensor) and idx.device == self.device:
+            if idx.dtype not in (torch.int32, torch.int64):
+                raise IndexError("%s tensor must be int32 or int64, not %s" % (what, idx.dtype))
+            if self.check_device_indices and bound is not None and idx.numel():
+                lo, hi = int(idx.min()), int(idx.max())          # synchronises: opt-in (OvnEngine.check_device_indices)
+                if lo < 0 or hi >= bound:
+                    raise IndexError("%s out of range: [%d, %d] not within [0, %d)" % (what, lo, hi, bound))
             t = idx.to(torch.int32).contiguous()
         else:
             a = np.ascontiguousarray(idx.cpu().numpy() if isinstance(idx, torch.Tensor) else idx).reshape(-1)

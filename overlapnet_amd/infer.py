@@ -35,18 +35,21 @@ class FeatureVolumeCache(object):
   """`Infer.feature_volumes`: behaves like the reference's Python list of (1, 360, 128) arrays (infer.py:114,185), but the
   volumes live in HBM (together with their spectra) and are copied to the host one at a time when indexed."""
 
-  def __init__(self, engine, as_array=False):
+  def __init__(self, engine, min_capacity=1024):
+    """min_capacity: smallest allocation (volumes) on first use -- 1024 (380 MB with the spectra) for the persistent cache of
+    `infer_multiple`, which grows by one frame per call; the throw-away caches of `infer_one` / `infer_multiple_vs_multiple`
+    pass the number of volumes they will hold."""
     self._engine = engine
     self._fv = None        # (capacity, 360, 128) device tensor
     self._spec = None      # (capacity, 128, 368) device tensor: cached spectra for the correlation head
     self._n = 0
-    self._as_array = as_array   # after infer_multiple_vs_multiple the reference holds an (n,1,360,128) ndarray (infer.py:220)
+    self._min_capacity = max(1, int(min_capacity))
 
   # -- device side ---------------------------------------------------------------------------------
   def extend_device(self, fv: torch.Tensor) -> None:
     k = fv.shape[0]
     if self._fv is None or self._n + k > self._fv.shape[0]:
-      cap = max(1024, 2 * (self._n + k))
+      cap = max(self._min_capacity, self._n + k if self._fv is None else 2 * (self._n + k))
       dev = self._engine.device
       nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
       ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
@@ -178,7 +181,7 @@ class Infer():
     self.engine.set_head_precision(self.precision)
 
     # previous feature volumes (infer.py:114): list-like view of the HBM-resident cache
-    self.feature_volumes = FeatureVolumeCache(self.engine)
+    self._feature_volumes = FeatureVolumeCache(self.engine)
 
     pretrained_weightsfilename = config['pretrained_weightsfilename']
     if weights is not None:
@@ -189,6 +192,27 @@ class Infer():
       print('Pre-trained weights was not found in:', pretrained_weightsfilename)
       w = W.keras_default_init(self.no_input_channels, self._model_cfg, seed)
     self.engine.load_weights(w, self._model_cfg)
+
+  @property
+  def feature_volumes(self):
+    """The cache of previous feature volumes (infer.py:114,185,220), resident in HBM."""
+    return self._feature_volumes
+
+  @feature_volumes.setter
+  def feature_volumes(self, value):
+    """`infer.feature_volumes = []` (the reference's way to reset the cache) or any list / ndarray of (1, 360, 128) host volumes
+    rebuilds the device cache from it; a FeatureVolumeCache is taken as is."""
+    if isinstance(value, FeatureVolumeCache):
+      self._feature_volumes = value
+      return
+    vols = np.asarray(value, dtype=np.float32) if len(value) else np.zeros((0, FEAT_W, FEAT_C), np.float32)
+    if vols.size % (FEAT_W * FEAT_C):
+      raise ValueError('feature volumes must have shape (n, 1, %d, %d)' % (FEAT_W, FEAT_C))
+    vols = np.ascontiguousarray(vols).reshape(-1, FEAT_W, FEAT_C)
+    cache = FeatureVolumeCache(self.engine)
+    if vols.shape[0]:
+      cache.extend_device(torch.from_numpy(vols).to(self.engine.device))
+    self._feature_volumes = cache
 
   # ------------------------------------------------------------------------------------------------
   # ---- inputs: channel stacking of ImagePairOverlapOrientationSequence.prepareOneInput (:130-207), depth -> normals -> class
@@ -318,7 +342,7 @@ class Infer():
     if not os.path.isdir(preprocess_data_folder):
       raise Exception('Please first generate preprocessed input data.')
 
-    pair = FeatureVolumeCache(self.engine)
+    pair = FeatureVolumeCache(self.engine, min_capacity=2)
     pair.extend_device(self._leg_device(list(self.filenames)))
     indizes = np.zeros((1, 2), dtype=int)
     indizes[0, 0] = 0
@@ -370,7 +394,7 @@ class Infer():
     if len(first_idxs) != len(second_idxs):
       raise Exception('Please make sure the first_idxs and second_idxs have the same size.')
     file_names = [os.path.basename(v).replace('.bin', '') for v in file_names]
-    self.feature_volumes = FeatureVolumeCache(self.engine, as_array=True)
+    self.feature_volumes = FeatureVolumeCache(self.engine, min_capacity=len(file_names))
     self.feature_volumes.extend_device(self._leg_device(file_names))
 
     if len(second_idxs) > 0:

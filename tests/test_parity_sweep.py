@@ -9,7 +9,8 @@ re-runs the oracle on a few pairs and requires equality with the file, so the fi
 
 Gates (north star): |d overlap| <= 1e-4 on every pair; yaw bin identical except where the ORACLE's own top-2 gap is
 below 1e-5 relative (listed in the report); |d logit| <= 1e-3 (1 + |logit|).
-The statistics go to gpurun_out/r2_parity_1024.json (copied to profiles/ when committed)."""
+The statistics go to gpurun_out/parity/<case>.json, one file per case; tools/collect_parity.py merges them into the tracked
+profiles/r<round>_parity.json."""
 import json
 import os
 
@@ -115,12 +116,12 @@ def test_sweep_every_pair_against_oracle(wset, C, POOL):
                 failures.append("%s: yaw bins differ on pairs with a clear maximum: %s" % (name, hard))
     finally:
         eng.close()
-    out_dir = os.path.join(ROOT, "gpurun_out")
+    # one report file per case (a fresh GPU box starts with an empty gpurun_out/, and partial runs must not overwrite each other);
+    # tools/collect_parity.py merges them into the tracked profiles/r<round>_parity.json
+    out_dir = os.path.join(ROOT, "gpurun_out", "parity")
     os.makedirs(out_dir, exist_ok=True)
-    path = os.path.join(out_dir, "r2_parity_1024.json")
-    allrep = json.load(open(path)) if os.path.isfile(path) else {}
-    allrep[wset if (C, POOL) == (4, 1024) else "%s_c%d_p%d" % (wset, C, POOL)] = report
-    json.dump(allrep, open(path, "w"), indent=1)
+    case = wset if (C, POOL) == (4, 1024) else "%s_c%d_p%d" % (wset, C, POOL)
+    json.dump(report, open(os.path.join(out_dir, case + ".json"), "w"), indent=1)
     assert not failures, failures
     # the default arithmetic has the error of an fp32 evaluation: within 2x of the all-fp32 mode (+ 2e-6 of fp32 noise floor)
     m = report["modes"]
