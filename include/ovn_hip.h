@@ -14,7 +14,8 @@
  *     ENQUEUES work on it, nothing synchronises unless stated.  One exception: a context owns ONE scratch
  *     block that grows on demand; a call that needs more than any earlier call synchronises `stream`
  *     once to re-allocate it.  All calls on one context must therefore be issued on one stream at a time
- *     (two streams would race on the scratch);
+ *     (two streams would race on the scratch).  A head call may internally fork onto context-owned side
+ *     streams; it joins them back into `stream` before it returns (events, no host synchronisation);
  *   - every entry point selects the context's device for its own duration and restores the caller's
  *     current HIP device before it returns;
  *   - return value 0 = success, non-zero = error, message via ovn_last_error() (thread-local);
@@ -111,6 +112,30 @@ int ovn_spectrum(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* spectra
 int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l_dev, const int32_t* lidx_dev, const float* spec_r_dev,
                            const int32_t* ridx_dev, int64_t n, int32_t* yaw_dev, float* corr_dev, void* stream);
 
+/* Both heads of a sweep whose candidates have their spectra cached next to their feature volumes: what `Infer.infer_multiple`
+ * runs per query.  Same outputs and indexing as ovn_heads (one index array addresses both the feature and the spectrum pool);
+ * the Delta head reads the feature volumes, the yaw head the spectra.  The HBM-bound yaw kernel and the matrix-core-bound Delta
+ * kernels are independent, so the call forks them over context-owned side streams and joins them back into `stream` with events
+ * before it returns control of the stream: to the caller everything is ordered as if enqueued on `stream`.
+ * Replaces `head.predict_generator` + post-processing for 1-vs-N sweeps (infer.py:188-198). */
+int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec_l_dev, const int32_t* lidx_dev,
+                       const float* feats_r_dev, const float* spec_r_dev, const int32_t* ridx_dev, int64_t n,
+                       float* overlap_dev, int32_t* yaw_dev, float* logit_dev, float* corr_dev, void* stream);
+
+/* Launch structure of the head calls (the reference's counterpart is `batch_size`, network.yml:41, which sets how many pairs one
+ * predict step materialises):
+ *   chunk_pairs          pairs per pass over the context's scratch (default 1024).  The f16x3 Delta path needs 3.2 MB of scratch
+ *                        per pair of a chunk (packed volumes, linear terms, the c_conv1 rows between its two kernels):
+ *                        ovn_workspace_bytes ~ 3.3 GB at the default; a sweep longer than a chunk is processed in several passes;
+ *   sub_chunk_pairs      0 = none; otherwise every chunk is cut into sub-chunks of this many pairs whose kernel chains
+ *                        alternate between `streams` (1 or 2) streams -- the prepare / c_conv2 / c_conv3 kernels of one sub-chunk
+ *                        then run beside the contraction kernel of the next;
+ *   yaw_on_side_stream   ovn_heads_spectral runs its yaw kernel on a side stream (default 1).
+ * Results do not depend on any of these (every pair is computed by the same kernels with per-pair scales). */
+int ovn_set_head_pipeline(ovn_ctx* ctx, int64_t chunk_pairs, int64_t sub_chunk_pairs, int streams, int yaw_on_side_stream);
+/* The current settings (any output pointer may be NULL). */
+int ovn_get_head_pipeline(ovn_ctx* ctx, int64_t* chunk_pairs, int64_t* sub_chunk_pairs, int* streams, int* yaw_on_side_stream);
+
 /* Loop-closure decision of a 1-vs-N sweep, on the device (demo/demo3_lcd.py:117-120:
  * `if np.max(overlaps) > overlap_thres: return reference_idx[np.argmax(overlaps)]`; first maximum wins, NaN never wins).
  *   overlap_dev (n) f32, yaw_dev (n) i32 or NULL: outputs of ovn_heads / ovn_delta_head (+ ovn_corr_head_spectral)
@@ -178,7 +203,7 @@ int ovn_profile_end(ovn_ctx* ctx, double* ms_by_kind, int64_t* launches_by_kind)
 int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, int w, float* out_dev, void* stream);
 
 /* Test hook: copy the c_conv2 (n,24,24,128) and c_conv3 (n,22,22,256) activations that the most recent
- * ovn_heads call left in scratch (its first chunk, n <= min(pairs, 2048)); either output may be NULL.
+ * ovn_heads call left in scratch (its first chunk / sub-chunk, n <= min(pairs, chunk_pairs, sub_chunk_pairs)); either output may be NULL.
  * (generateNet.py:102-110 intermediates; the reference exposes them as Keras layer outputs.) */
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream);
 

@@ -34,6 +34,9 @@ SIGNATURES = {
     "ovn_corr_head": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "ovn_spectrum": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "ovn_corr_head_spectral": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "ovn_heads_spectral": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "ovn_set_head_pipeline": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
+    "ovn_get_head_pipeline": (C.c_int, [_vp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ovn_best_match": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_int64, _vp, _vp]),
     "ovn_project": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                               C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),

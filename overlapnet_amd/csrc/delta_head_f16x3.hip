@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 template <int SPC, int ABL = 0>
 __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __restrict__ pl, const unsigned* __restrict__ pr,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
-                                                             float* __restrict__ o1raw, int rot, int nsplit) {
+                                                             float* __restrict__ o1raw, int rot, int nsplit, int pair0) {
   constexpr int CHB = SPC * STEP_BYTES;          // window chunk
   constexpr int CPS = S / SPC;                   // chunks per channel slice
   constexpr int NCH = 4 * CPS;                   // chunks per walk of K
@@ -629,7 +629,9 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
     if (wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
   }
 
-  const int s0 = rot ? ((pair >> 3) & 3) : 0;
+  // rotation of the K walk by the pair's index in the SWEEP (pair0 = index of this launch's first pair): the summation order of a
+  // pair, and with it the last bits of its result, does not depend on how the sweep is cut into launches
+  const int s0 = rot ? (((pair0 + pair) >> 3) & 3) : 0;
   const int p_begin = part * (G / 2) / nsplit, p_end = (part + 1) * (G / 2) / nsplit;
   int cur = 0, rcur = 0;
   int chunk = CPS * s0;
@@ -891,7 +893,8 @@ static int pick_nsplit(int n) {
 
 // a2 + prepare (profile class delta_prep), c_conv1 contraction (delta_c12), c_conv2 GEMM (delta_c2)
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream) {
+                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream,
+                                int pair0) {
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel), PREP_SPLIT_LDS);
   if (rc) return rc;
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -927,7 +930,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), lds);              \
     if (rc) return rc;                                                                                                       \
     hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, pl, pr,       \
-                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit);                             \
+                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0);                      \
   }
 #ifdef OVN_ABLATE
     switch (getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0) {   // tools/experiments/c1_variants.py

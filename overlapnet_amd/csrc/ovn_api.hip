@@ -5,6 +5,7 @@
 #include <set>
 #include <utility>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ovn_internal.h"
@@ -72,6 +73,11 @@ int ovn_create(int device_id, int in_h, int in_w, int in_c, ovn_ctx** out) {
   c->in_h = in_h;
   c->in_w = in_w;
   c->in_c = in_c;
+  // experiment knobs (tools/experiments): the defaults are the measured best, ovn_set_head_pipeline is the API
+  if (const char* e = getenv("OVN_HEAD_CHUNK")) c->head_chunk = atoll(e) > 0 ? atoll(e) : c->head_chunk;
+  if (const char* e = getenv("OVN_HEAD_SUBCHUNK")) c->head_sub = atoll(e) >= 0 ? atoll(e) : c->head_sub;
+  if (const char* e = getenv("OVN_HEAD_STREAMS")) c->head_streams = atoi(e) == 2 ? 2 : 1;
+  if (const char* e = getenv("OVN_YAW_SIDE")) c->head_yaw_side = atoi(e) ? 1 : 0;
   int rc = ovn_spectral_prepare(c, nullptr);
   if (rc) {
     ovn_conv_release(&c->dft);
@@ -106,6 +112,13 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->w2sum) (void)hipFree(ctx->w2sum);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->actmax) (void)hipFree(ctx->actmax);
+  if (ctx->aux_ready) {
+    for (int i = 0; i < 2; ++i) {
+      (void)hipStreamDestroy(ctx->aux[i]);
+      (void)hipEventDestroy(ctx->ev_join[i]);
+    }
+    (void)hipEventDestroy(ctx->ev_fork);
+  }
   delete ctx;
   return OVN_OK;
 }
@@ -321,72 +334,164 @@ int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l, const int32_t* lid
   return ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, (hipStream_t)stream);
 }
 
-// Delta (overlap) head on n pairs, chunked over the scratch; shared by ovn_heads and ovn_delta_head.
+// ---- side streams of a head call -----------------------------------------------------------------------------------------------
+// A head call may spread its launches over the caller's stream and two context-owned side streams: the HBM-bound yaw head next to
+// the matrix-core-bound Delta kernels, and the sub-chunks of a sweep alternating between two streams so that the prepare / c_conv2 /
+// c_conv3 kernels of one sub-chunk run beside the contraction kernel of the next.  Fork and join are events on the caller's stream:
+// to the caller the call still behaves as if everything had been enqueued on `stream` (and it can be captured in a HIP graph).
+static int head_streams_ready(ovn_ctx* ctx) {
+  if (ctx->aux_ready) return OVN_OK;
+  for (int i = 0; i < 2; ++i) {
+    OVN_HIP_CHECK(hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking));
+    OVN_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_join[i], hipEventDisableTiming));
+  }
+  OVN_HIP_CHECK(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  ctx->aux_ready = true;
+  return OVN_OK;
+}
+
+struct OvnFork {   // fork on construction-time request, join (on every exit path) in the destructor
+  ovn_ctx* ctx;
+  hipStream_t stream;
+  bool used[2] = {false, false};
+  bool forked = false;
+  OvnFork(ovn_ctx* c, hipStream_t s) : ctx(c), stream(s) {}
+  int fork() {
+    if (forked) return OVN_OK;
+    int rc = head_streams_ready(ctx);
+    if (rc) return rc;
+    OVN_HIP_CHECK(hipEventRecord(ctx->ev_fork, stream));
+    forked = true;
+    return OVN_OK;
+  }
+  // side stream i, ordered behind everything the caller had enqueued on `stream` when fork() ran
+  int side(int i, hipStream_t* out) {
+    int rc = fork();
+    if (rc) return rc;
+    if (!used[i]) {
+      OVN_HIP_CHECK(hipStreamWaitEvent(ctx->aux[i], ctx->ev_fork, 0));
+      used[i] = true;
+    }
+    *out = ctx->aux[i];
+    return OVN_OK;
+  }
+  int join() {
+    int rc = OVN_OK;
+    for (int i = 0; i < 2; ++i)
+      if (used[i]) {
+        used[i] = false;
+        if (hipEventRecord(ctx->ev_join[i], ctx->aux[i]) != hipSuccess || hipStreamWaitEvent(stream, ctx->ev_join[i], 0) != hipSuccess) {
+          ovn_set_error("joining the head's side stream failed");
+          rc = OVN_ERR_HIP;
+        }
+      }
+    return rc;
+  }
+  ~OvnFork() { (void)join(); }
+};
+
+// Delta (overlap) head on n pairs [+ one of the correlation heads]; shared by ovn_heads, ovn_delta_head and ovn_heads_spectral.
+//   corr_mode 0: none; 1: direct form on the feature volumes (per chunk, on the caller's stream, as ovn_heads always did);
+//             2: spectral form on (spec_l, spec_r): ONE launch for all n pairs on a side stream, beside the Delta kernels.
+// The sweep is cut into chunks of <= ctx->head_chunk pairs (the scratch is sized for one chunk) and every chunk into sub-chunks of
+// ctx->head_sub pairs that alternate between ctx->head_streams streams (sub-chunk j of every chunk uses scratch region j and
+// stream j % streams, so a region is only ever reused in stream order).
 static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                           const int32_t* ridx, int64_t n, float* overlap, float* logit, int32_t* yaw, float* corr,
-                          bool with_corr, hipStream_t stream) {
+                          int corr_mode, const float* spec_l, const float* spec_r, hipStream_t stream) {
   const size_t o2_elems = (size_t)OVN_G * OVN_G * OVN_C2_OUT;   // 24*24*128 per pair
   const size_t o3_elems = (size_t)OVN_DENSE_IN;                 // 22*22*256 per pair
-  const int64_t chunk = 2048;                                   // pairs per pass: 6.6 GB of scratch in f16x3 mode
+  const bool fused = (ctx->head_mode != 0);
+  const int64_t chunk = ctx->head_chunk;                        // pairs per pass over the scratch (f16x3: 3.2 MB per pair)
   const int64_t cmax = n < chunk ? n : chunk;
-  const size_t o2_bytes = ((size_t)cmax * o2_elems * sizeof(float) + 255) & ~(size_t)255;
+  // sub-chunks: only the f16x3 kernels are split (the fp32 mode is one long kernel per chunk and keeps the round-2 structure)
+  int64_t sub = (fused && ctx->head_sub > 0 && ctx->head_sub < cmax) ? ctx->head_sub : cmax;
+  const int nsub_max = (int)((cmax + sub - 1) / sub);
+  const int nstreams = (fused && nsub_max > 1 && ctx->head_streams > 1) ? 2 : 1;
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t o2_bytes = al((size_t)cmax * o2_elems * sizeof(float));
   // second scratch region: o3 (n,22,22,256) in fp32 mode; in f16x3 mode c_conv3 and the Dense layer are one kernel and only
   // 3 partial sums per pair leave it
-  const bool fused = (ctx->head_mode != 0);
-  const size_t o3_bytes = fused ? (((size_t)cmax * 3 * sizeof(float) + 255) & ~(size_t)255)
-                                : (((size_t)cmax * o3_elems * sizeof(float) + 255) & ~(size_t)255);
-  // f16x3 mode: per-pair scales, packed volumes, linear terms and the c_conv1 rows between the two Delta kernels (2.9 MB per pair)
-  const size_t sc_bytes = fused ? ovn_delta_f16x3_scratch_bytes((int)cmax, ridx != nullptr) : 0;
-  int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes + sc_bytes, stream);
+  const size_t o3_bytes = fused ? al((size_t)cmax * 3 * sizeof(float)) : al((size_t)cmax * o3_elems * sizeof(float));
+  // f16x3 mode: per-pair scales, packed volumes, linear terms and the c_conv1 rows between the two Delta kernels (2.9 MB per pair),
+  // one self-contained block per sub-chunk
+  const size_t sc_sub = fused ? al(ovn_delta_f16x3_scratch_bytes((int)sub, ridx != nullptr)) : 0;
+  int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes + sc_sub * nsub_max, stream);
   if (rc) return rc;
   float* o2 = reinterpret_cast<float*>(ctx->ws);
   float* o3 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + o2_bytes);
-  void* dscratch = static_cast<char*>(ctx->ws) + o2_bytes + o3_bytes;
-  unsigned* o2max = nullptr;
+  char* dscratch = static_cast<char*>(ctx->ws) + o2_bytes + o3_bytes;
   ctx->dbg_o2max = nullptr;
   ctx->dbg_o2 = o2;
   ctx->dbg_o3 = fused ? nullptr : o3;
   ctx->dbg_partial = fused ? o3 : nullptr;
-  ctx->dbg_n = cmax;
-  for (int64_t p0 = 0; p0 < n; p0 += chunk) {
-    const int np = (int)((n - p0 < chunk) ? (n - p0) : chunk);
-    const float* fl = lidx ? feats_l : feats_l + (size_t)p0 * OVN_FEAT_ELEMS;
-    const int32_t* li = lidx ? lidx + p0 : nullptr;
-    const int32_t* ri = ridx ? ridx + p0 : nullptr;
-    if (with_corr) {
-      OvnProfScope ps(ctx, OVN_K_CORR, stream);
-      rc = ovn_corr_forward(fl, li, feats_r, ri, np, yaw + p0, corr ? corr + (size_t)p0 * OVN_FEAT_W : nullptr, stream);
+  ctx->dbg_n = sub < cmax ? sub : cmax;      // the activations of the first sub-chunk stay addressable for the tests
+
+  OvnFork fk(ctx, stream);
+  if (corr_mode == 2) {
+    hipStream_t ys = stream;
+    if (ctx->head_yaw_side) {
+      rc = fk.side(1, &ys);
       if (rc) return rc;
     }
-    if (fused) {   // times its prepare kernels and the main kernel separately
-      rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch, &o2max, o2, stream);
-      if (p0 == 0) ctx->dbg_o2max = o2max;
-    } else {
-      OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-      rc = ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2, stream);
-    }
-    if (rc) return rc;
-    if (fused) {
-      {
-        OvnProfScope ps(ctx, OVN_K_C3, stream);
-        rc = ovn_c3_dense_forward(ctx, o2, o2max, np, o3, nullptr, stream);
-      }
-      if (rc) return rc;
-      OvnProfScope ps(ctx, OVN_K_DENSE, stream);
-      rc = ovn_dense_finish_forward(ctx, o3, np, overlap + p0, logit ? logit + p0 : nullptr, stream);
-    } else {
-      int oh = 0, ow = 0;
-      {
-        OvnProfScope ps(ctx, OVN_K_C3, stream);
-        rc = ovn_conv_forward(ctx->c3, o2, np, OVN_G, OVN_G, o3, &oh, &ow, stream);
-      }
-      if (rc) return rc;
-      OvnProfScope ps(ctx, OVN_K_DENSE, stream);
-      rc = ovn_dense_sigmoid_forward(ctx, o3, np, overlap + p0, logit ? logit + p0 : nullptr, stream);
-    }
+    OvnProfScope ps(ctx, OVN_K_CORR_SPECTRAL, ys);
+    rc = ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, ys);
     if (rc) return rc;
   }
-  return OVN_OK;
+  for (int64_t c0 = 0; c0 < n; c0 += chunk) {
+    const int64_t cn = (n - c0 < chunk) ? (n - c0) : chunk;
+    if (corr_mode == 1) {
+      OvnProfScope ps(ctx, OVN_K_CORR, stream);
+      rc = ovn_corr_forward(lidx ? feats_l : feats_l + (size_t)c0 * OVN_FEAT_ELEMS, lidx ? lidx + c0 : nullptr, feats_r,
+                            ridx ? ridx + c0 : nullptr, (int)cn, yaw + c0, corr ? corr + (size_t)c0 * OVN_FEAT_W : nullptr, stream);
+      if (rc) return rc;
+    }
+    int j = 0;
+    for (int64_t q0 = 0; q0 < cn; q0 += sub, ++j) {
+      const int64_t p0 = c0 + q0;
+      const int np = (int)((cn - q0 < sub) ? (cn - q0) : sub);
+      hipStream_t st = stream;
+      if (nstreams == 2 && (j & 1)) {
+        rc = fk.side(0, &st);
+        if (rc) return rc;
+      }
+      const float* fl = lidx ? feats_l : feats_l + (size_t)p0 * OVN_FEAT_ELEMS;
+      const int32_t* li = lidx ? lidx + p0 : nullptr;
+      const int32_t* ri = ridx ? ridx + p0 : nullptr;
+      float* o2s = o2 + (size_t)q0 * o2_elems;
+      if (fused) {   // times its prepare kernels, the contraction kernel and c_conv2 separately
+        unsigned* o2max = nullptr;
+        float* part = o3 + (size_t)q0 * 3;
+        rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff));
+        if (rc) return rc;
+        if (p0 == 0) ctx->dbg_o2max = o2max;
+        {
+          OvnProfScope ps(ctx, OVN_K_C3, st);
+          rc = ovn_c3_dense_forward(ctx, o2s, o2max, np, part, nullptr, st);
+        }
+        if (rc) return rc;
+        OvnProfScope ps(ctx, OVN_K_DENSE, st);
+        rc = ovn_dense_finish_forward(ctx, part, np, overlap + p0, logit ? logit + p0 : nullptr, st);
+      } else {
+        float* o3s = o3 + (size_t)q0 * o3_elems;
+        {
+          OvnProfScope ps(ctx, OVN_K_DELTA, st);
+          rc = ovn_delta_c12_forward(ctx, fl, li, feats_r, ri, np, o2s, st);
+        }
+        if (rc) return rc;
+        int oh = 0, ow = 0;
+        {
+          OvnProfScope ps(ctx, OVN_K_C3, st);
+          rc = ovn_conv_forward(ctx->c3, o2s, np, OVN_G, OVN_G, o3s, &oh, &ow, st);
+        }
+        if (rc) return rc;
+        OvnProfScope ps(ctx, OVN_K_DENSE, st);
+        rc = ovn_dense_sigmoid_forward(ctx, o3s, np, overlap + p0, logit ? logit + p0 : nullptr, st);
+      }
+      if (rc) return rc;
+    }
+  }
+  return fk.join();
 }
 
 int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
@@ -396,7 +501,18 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads: NULL buffer");
   OVN_ON_DEVICE(ctx->device);
-  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, true, (hipStream_t)stream_);
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, 1, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l, const float* spec_l, const int32_t* lidx, const float* feats_r,
+                       const float* spec_r, const int32_t* ridx, int64_t n, float* overlap, int32_t* yaw, float* logit, float* corr,
+                       void* stream_) {
+  OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_heads_spectral: head weights not set");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_heads_spectral: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(feats_l && feats_r && spec_l && spec_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads_spectral: NULL buffer");
+  OVN_ON_DEVICE(ctx->device);
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, 2, spec_l, spec_r, (hipStream_t)stream_);
 }
 
 int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
@@ -406,7 +522,28 @@ int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, cons
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && overlap, OVN_ERR_ARG, "ovn_delta_head: NULL buffer");
   OVN_ON_DEVICE(ctx->device);
-  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, false, (hipStream_t)stream_);
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, 0, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+int ovn_set_head_pipeline(ovn_ctx* ctx, int64_t chunk_pairs, int64_t sub_chunk_pairs, int streams, int yaw_on_side_stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_pipeline: ctx is NULL");
+  OVN_REQUIRE(chunk_pairs >= 1 && chunk_pairs <= (1 << 20), OVN_ERR_ARG, "ovn_set_head_pipeline: chunk_pairs %lld", (long long)chunk_pairs);
+  OVN_REQUIRE(sub_chunk_pairs >= 0, OVN_ERR_ARG, "ovn_set_head_pipeline: sub_chunk_pairs %lld", (long long)sub_chunk_pairs);
+  OVN_REQUIRE(streams == 1 || streams == 2, OVN_ERR_ARG, "ovn_set_head_pipeline: streams %d (1 or 2)", streams);
+  ctx->head_chunk = chunk_pairs;
+  ctx->head_sub = sub_chunk_pairs;
+  ctx->head_streams = streams;
+  ctx->head_yaw_side = yaw_on_side_stream ? 1 : 0;
+  return OVN_OK;
+}
+
+int ovn_get_head_pipeline(ovn_ctx* ctx, int64_t* chunk_pairs, int64_t* sub_chunk_pairs, int* streams, int* yaw_on_side_stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_get_head_pipeline: ctx is NULL");
+  if (chunk_pairs) *chunk_pairs = ctx->head_chunk;
+  if (sub_chunk_pairs) *sub_chunk_pairs = ctx->head_sub;
+  if (streams) *streams = ctx->head_streams;
+  if (yaw_on_side_stream) *yaw_on_side_stream = ctx->head_yaw_side;
+  return OVN_OK;
 }
 
 int ovn_best_match(ovn_ctx* ctx, const float* overlap, const int32_t* yaw, const int32_t* ids, int64_t n, float threshold,

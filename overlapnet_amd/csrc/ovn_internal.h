@@ -145,6 +145,15 @@ struct ovn_ctx {
   // optional RCCL communicator of the sharded sweep (comm.hip)
   void* comm = nullptr;
   int comm_rank = 0, comm_world = 1;
+  // launch structure of a head call (ovn_set_head_pipeline): pairs per pass over the scratch, pairs per sub-chunk (0 = the whole
+  // chunk), streams the sub-chunks alternate between (1 or 2), spectral yaw head on its own side stream
+  int64_t head_chunk = 1024;
+  int64_t head_sub = 0;
+  int head_streams = 1;
+  int head_yaw_side = 1;
+  bool aux_ready = false;
+  hipStream_t aux[2] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
   // scratch
   void* ws = nullptr;
   size_t ws_bytes = 0;
@@ -218,7 +227,8 @@ int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const floa
                             hipStream_t stream);
 size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right);
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
-                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream);
+                                const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream,
+                                int pair0 = 0);   // pair0: index of the call's first pair in the sweep (rotation of the K walks)
 
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,

@@ -176,15 +176,22 @@ class OvnEngine:
             # cached spectra given: Delta head on the features, correlation head in its HBM-bound spectral form
             if spec_l is None or spec_r is None:
                 raise _lib.OvnError("spec_l and spec_r must be given together")
+            for t, what in ((spec_l, "spec_l"), (spec_r, "spec_r")):
+                if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+                    raise _lib.OvnError("%s must be a contiguous float32 tensor on %s" % (what, self.device))
+            if spec_l.numel() != nl * FEAT_C * self.SPEC_W or spec_r.numel() != nr * FEAT_C * self.SPEC_W:
+                raise _lib.OvnError("spec_l / spec_r must hold one 128x368 spectrum per feature volume")
+            yaw = torch.empty(n, dtype=torch.int32, device=self.device)
+            corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
             with torch.cuda.device(self.device):
-                _lib.check(self.lib.ovn_delta_head(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n,
-                                                   _ptr(overlap), _ptr(logit), self._stream()), "ovn_delta_head")
-            c = self.corr_head_spectral(spec_l, spec_r, lidx=li, ridx=ri, n=n, want_corr=want_corr)
-            out = {"overlap": overlap, "yaw": c["yaw"]}
+                _lib.check(self.lib.ovn_heads_spectral(self._h, _ptr(feats_l), _ptr(spec_l), _ptr(li), _ptr(feats_r), _ptr(spec_r),
+                                                       _ptr(ri), n, _ptr(overlap), _ptr(yaw), _ptr(logit), _ptr(corr),
+                                                       self._stream()), "ovn_heads_spectral")
+            out = {"overlap": overlap, "yaw": yaw}
             if want_logit:
                 out["logit"] = logit
             if want_corr:
-                out["corr"] = c["corr"]
+                out["corr"] = corr
             return out
         yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
@@ -350,6 +357,17 @@ class OvnEngine:
             _lib.check(self.lib.ovn_debug_head_activations(self._h, n, _ptr(o2), _ptr(o3), self._stream()),
                        "ovn_debug_head_activations")
         return o2, o3
+
+    def set_head_pipeline(self, chunk_pairs: int = 1024, sub_chunk_pairs: int = 0, streams: int = 1, yaw_on_side_stream: bool = True):
+        """Launch structure of the head calls (include/ovn_hip.h: ovn_set_head_pipeline); results do not depend on it."""
+        _lib.check(self.lib.ovn_set_head_pipeline(self._h, int(chunk_pairs), int(sub_chunk_pairs), int(streams),
+                                                  int(bool(yaw_on_side_stream))), "ovn_set_head_pipeline")
+
+    def head_pipeline(self):
+        """(chunk_pairs, sub_chunk_pairs, streams, yaw_on_side_stream) currently in effect."""
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int(), C.c_int()
+        _lib.check(self.lib.ovn_get_head_pipeline(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "ovn_get_head_pipeline")
+        return int(a.value), int(b.value), int(c.value), bool(d.value)
 
     def set_head_precision(self, mode: str) -> None:
         """Arithmetic of the Delta-head contractions (fp32 storage and accumulation in both modes):

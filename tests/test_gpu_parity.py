@@ -767,3 +767,47 @@ def test_100k_candidate_sweep_properties(engines):
     ov = r["overlap"].cpu().numpy()
     k = int(np.argmax(ov))
     assert decode_match(rec) == (k, float(ov[k]), int(yaw[k]))
+
+
+def test_head_results_do_not_depend_on_the_launch_structure(engines):
+    """ovn_set_head_pipeline (chunk / sub-chunk sizes, one or two streams, yaw head on a side stream) changes WHEN kernels run,
+    never what they compute: every pair gets the same bits; and ovn_heads_spectral == ovn_delta_head + ovn_corr_head_spectral."""
+    from overlapnet_amd import _lib
+    e = engines[4]
+    rng = np.random.default_rng(123)
+    n = 700
+    fv = torch.from_numpy(np.maximum(rng.normal(0.2, 1.0, size=(n, 360, 128)), 0).astype(np.float32)).cuda()
+    q = fv[11:12].contiguous()
+    spec, qspec = e.spectrum(fv), e.spectrum(q)
+    DEFAULT_PIPELINE = e.head_pipeline()
+    try:
+        e.set_head_pipeline(1024, 0, 1, False)                      # one chunk, one stream, everything in order
+        ref = e.heads(fv, q, spec_l=spec, spec_r=qspec, want_logit=True, want_corr=True)
+        ov = torch.empty(n, device="cuda")
+        lg = torch.empty(n, device="cuda")
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(e.lib.ovn_delta_head(e._h, fv.data_ptr(), None, q.data_ptr(), None, n, ov.data_ptr(), lg.data_ptr(), st), "ovn_delta_head")
+        sep = e.corr_head_spectral(spec, qspec, want_corr=True)
+        assert torch.equal(ov, ref["overlap"]) and torch.equal(lg, ref["logit"])
+        assert torch.equal(sep["yaw"], ref["yaw"]) and torch.equal(sep["corr"], ref["corr"])
+        idx = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
+        ref_idx = e.heads(fv, q, lidx=idx, spec_l=spec, spec_r=qspec, want_logit=True)
+        assert torch.equal(ref_idx["logit"], ref["logit"][idx.long()]) or \
+            torch.allclose(ref_idx["logit"], ref["logit"][idx.long()], rtol=2e-5, atol=2e-5)   # (K-walk rotation follows the position)
+        for cfg in ((1024, 256, 1, True), (1024, 256, 2, True), (1024, 100, 2, False), (300, 64, 2, True), (128, 0, 1, True),
+                    (256, 96, 2, True)):
+            e.set_head_pipeline(*cfg)
+            r = e.heads(fv, q, spec_l=spec, spec_r=qspec, want_logit=True, want_corr=True)
+            torch.cuda.synchronize()
+            for k in ("overlap", "logit", "yaw", "corr"):
+                assert torch.equal(r[k], ref[k]), (cfg, k)
+            r2 = e.heads(fv, q, lidx=idx, spec_l=spec, spec_r=qspec, want_logit=True)
+            assert torch.equal(r2["logit"], ref_idx["logit"]) and torch.equal(r2["yaw"], ref_idx["yaw"]), cfg
+            d = e.heads(fv, q, want_logit=True)                      # direct correlation form through the same pipeline
+            assert torch.equal(d["logit"], ref["logit"]), cfg
+        with pytest.raises(Exception):
+            e.set_head_pipeline(0, 0, 1, True)
+        with pytest.raises(Exception):
+            e.set_head_pipeline(1024, 0, 3, True)
+    finally:
+        e.set_head_pipeline(*DEFAULT_PIPELINE)
