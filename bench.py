@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the OverlapNet hot path on MI355X -- BASELINE.json metric: scan-pairs/s on 64x900 range images.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pool P] [--channels C]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pool P] [--channels C]     (N > 1: spawns one rank per GPU itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One STEP = one loop-closure query the way the reference's `Infer.infer_multiple` runs it
@@ -13,7 +13,9 @@ N = 1 (default): P = 1024 candidates, C = 4 = BASELINE.json configs[1] ("batched
 `value` is that warm sweep.  The same run then measures, each in its own timed region and reported as sub-records of the
 ONE JSON line: `fp32_mode` (every contraction on the fp32 matrix cores), `cold` (candidate legs inside the step),
 `fullstack` (raw clouds -> projection -> legs -> heads), `corr_head` (the HBM-bound correlation head alone at N = 1024 and
-16384), and the accuracy of the timed configuration over ALL pairs against the committed fp64-oracle outputs.
+16384), `infer_api` (BASELINE configs[2]: the 1101-frame loop-closure sweep through `Infer.infer_multiple`), `latency` (one query
+against N = 1 [configs[0]], 16, 100, 256 candidates), and the accuracy of the timed configuration over ALL pairs against the
+committed fp64-oracle outputs.
 
 N > 1: BASELINE.json configs[3], STRONG scaling: one 1-vs-100000 synthetic candidate pool (`--pool-total`) sharded in
 contiguous blocks over the ranks (overlapnet_amd.distributed.shard_bounds), feature volumes generated on the device
@@ -493,19 +495,49 @@ def main():
                                "frac_of_8TBps": n_c * CAND_BYTES_PER_PAIR / (ms * 1e-3) / PEAK_HBM_BPS,
                                "frac_of_8TBps_streamed": n_c * SPEC_BYTES_PER_PAIR / (ms * 1e-3) / PEAK_HBM_BPS}
             del f, sp
+        if spectral and prof.get("corr_spectral", (0, 0))[1]:
+            ms_in = prof["corr_spectral"][0] / prof["corr_spectral"][1]
+            ch["in_step_n%d" % P] = {"ms": ms_in, "frac_of_8TBps": P * CAND_BYTES_PER_PAIR / (ms_in * 1e-3) / PEAK_HBM_BPS,
+                                     "note": "the yaw kernel inside the timed warm step (between the Delta kernels' 8.9 GB of traffic: "
+                                             "nothing of the candidate spectra survives in the Infinity Cache from one step to the next)"}
+        ch["n1024"]["infinity_cache_resident"] = True   # 193 MB of spectra re-read by back-to-back launches: not an HBM figure
         ch["note"] = ("spectral form on cached candidate spectra; `frac_of_8TBps` prices SURVEY.md 8d's algorithmic bytes (184,328 B per "
                       "pair), `..._streamed` the 188,420 B the kernel actually reads and writes per pair; ms = HIP events around the launch(es)")
         out["corr_head"] = ch
-        # (5) the drop-in API end to end: streaming sweep through `Infer.infer_multiple` (files on disk -> results on the host)
-        #     next to the same sweep at engine level (device-resident inputs), tools/bench_infer_api.py
+        # (5) BASELINE configs[2]: the loop-closure sweep of a whole sequence through the drop-in API -- 1101 frames (KITTI 07's length,
+        #     emulated with synthetic scans), frame i against ALL i cached frames (605,550 pairs) via
+        #     `Infer.infer_multiple` (files on disk -> results on the host), next to the same sweep at engine level
+        #     (device-resident inputs, decision on the device), tools/bench_infer_api.py
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         from bench_infer_api import api_sweep, engine_sweep
-        fr = 400
+        fr = 1101
         es, aps = engine_sweep(fr, C), api_sweep(fr, "multiple")
         out["infer_api"] = {"frames": fr, "pairs": aps["pairs"], "api_frames_per_s": aps["frames_per_s"], "api_pairs_per_s": aps["pairs_per_s"],
-                            "engine_frames_per_s": es["frames_per_s"], "engine_pairs_per_s": es["pairs_per_s"],
-                            "api_over_engine": aps["frames_per_s"] / es["frames_per_s"],
+                            "api_seconds": aps["seconds"], "engine_frames_per_s": es["frames_per_s"], "engine_pairs_per_s": es["pairs_per_s"],
+                            "engine_seconds": es["seconds"], "api_over_engine": aps["frames_per_s"] / es["frames_per_s"],
+                            "workload": "BASELINE configs[2] (1-vs-all-previous over 1101 frames, ungated)",
                             "step": "frame i: np.load depth+normal .npy, H2D, leg, spectrum, both heads vs ALL i cached frames, results to host"}
+        # (6) BASELINE configs[0] and small gated sweeps: latency of ONE query against N cached candidates -- query leg + spectrum +
+        #     both heads + the on-device decision, the 16-byte record read back by the host every query (demo2: N = 1; demo3 after
+        #     gating: tens of candidates)
+        from overlapnet_amd.engine import decode_match
+        lat = {}
+        for n_c in (1, 16, 100, 256):
+            def q_step():
+                eng.leg(query_img, out=query_fv)
+                eng.spectrum(query_fv, out=query_spec)
+                r = eng.heads(cands[:n_c], query_fv, spec_l=cand_spec[:n_c], spec_r=query_spec)
+                return decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3))
+            for _ in range(5):
+                q_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                q_step()
+            torch.cuda.synchronize()
+            lat["n%d" % n_c] = {"ms_per_query": 1e3 * (time.perf_counter() - t0) / 50}
+        lat["note"] = "host wall clock per query incl. the device-to-host read of the decision; N = 1 is BASELINE configs[0] (demo2's single pair)"
+        out["latency"] = lat
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, P)
     print(json.dumps(out), flush=True)

@@ -73,9 +73,10 @@ int ovn_finalize(ovn_ctx* ctx, int* feat_w);
 
 /* Leg: images_dev (n, in_h, in_w, in_c) -> features_dev (n, feat_w, 128).
  * Replaces `leg.predict_generator` in Infer.create_feature_volumes (infer.py:262-265).
- * Every scan of one call takes the same kernels (results do not depend on the position in the batch); calls of <= 8 scans
- * use latency-oriented split-K kernels whose summation order differs from the batched ones (equal to fp32 rounding;
- * bit-identical across call sizes in fp32 mode, ovn_set_leg_precision(ctx, 0)). */
+ * A scan's feature volume depends on that scan alone: every call size runs the same kernels, and the power-of-two scales of the
+ * f16x3 arithmetic are taken per scan (per strip / tile inside the first layer and the fused tail) -- the same scan computed alone,
+ * inside any batch, at any position and next to any other scans gives the same bits (the reference's `predict_generator` results
+ * do not depend on batch composition either, infer.py:262-265). */
 int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_dev, void* stream);
 
 /* Both heads on n pairs.  Pair p uses l = feats_l_dev[lidx[p]] and r = feats_r_dev[ridx[p]]
@@ -114,9 +115,9 @@ int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l_dev, const int32_t*
 
 /* Both heads of a sweep whose candidates have their spectra cached next to their feature volumes: what `Infer.infer_multiple`
  * runs per query.  Same outputs and indexing as ovn_heads (one index array addresses both the feature and the spectrum pool);
- * the Delta head reads the feature volumes, the yaw head the spectra.  The HBM-bound yaw kernel and the matrix-core-bound Delta
- * kernels are independent, so the call forks them over context-owned side streams and joins them back into `stream` with events
- * before it returns control of the stream: to the caller everything is ordered as if enqueued on `stream`.
+ * the Delta head reads the feature volumes, the yaw head the spectra (ONE launch for the whole sweep).  With
+ * ovn_set_head_pipeline the call can fork the independent kernel chains over context-owned side streams; it joins them back into
+ * `stream` with events before it returns: to the caller everything is ordered as if enqueued on `stream`.
  * Replaces `head.predict_generator` + post-processing for 1-vs-N sweeps (infer.py:188-198). */
 int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec_l_dev, const int32_t* lidx_dev,
                        const float* feats_r_dev, const float* spec_r_dev, const int32_t* ridx_dev, int64_t n,
@@ -130,8 +131,11 @@ int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec
  *   sub_chunk_pairs      0 = none; otherwise every chunk is cut into sub-chunks of this many pairs whose kernel chains
  *                        alternate between `streams` (1 or 2) streams -- the prepare / c_conv2 / c_conv3 kernels of one sub-chunk
  *                        then run beside the contraction kernel of the next;
- *   yaw_on_side_stream   ovn_heads_spectral runs its yaw kernel on a side stream (default 1).
- * Results do not depend on any of these (every pair is computed by the same kernels with per-pair scales). */
+ *   yaw_on_side_stream   ovn_heads_spectral runs its yaw kernel on a side stream.
+ * Defaults: 1024, 0, 1, 0 -- the serial order.  Measured on MI355X (profiles/r3a_pipeline_matrix.md): the contraction kernel
+ * occupies every CU completely (256 registers x 8 waves, 126 KB of LDS), so kernels of a second stream only run in the gaps
+ * between its workgroups and none of the forked forms is faster than the serial one; the knobs remain for sweeps whose
+ * kernels leave room.  Results do not depend on any of these (every pair is computed by the same kernels with per-pair scales). */
 int ovn_set_head_pipeline(ovn_ctx* ctx, int64_t chunk_pairs, int64_t sub_chunk_pairs, int streams, int yaw_on_side_stream);
 /* The current settings (any output pointer may be NULL). */
 int ovn_get_head_pipeline(ovn_ctx* ctx, int64_t* chunk_pairs, int64_t* sub_chunk_pairs, int* streams, int* yaw_on_side_stream);

@@ -28,8 +28,8 @@ struct ConvArgsB {
   const _Float16* wp;   // [nkc][Cout/16][hi,lo][64][8], scaled by sw
   const float* bias;
   float* out;
-  const unsigned* in_max;   // float bits of max |input| (device), written by the producer of `in`
-  unsigned* out_max;        // NULL, or where this layer folds max |output| (atomicMax on the float bits)
+  const unsigned* in_max;   // [scan] float bits of max |input| of every scan (device), written by the producer of `in`
+  unsigned* out_max;        // NULL, or [scan]: where this layer folds max |output| of every scan (atomicMax on the float bits)
   float sw;                 // power-of-two scale of wp
   int H, W, Cin, OH, OW, Cout, SH, SW;
   int K, nkc, KWC, rowstride;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void split_pair_f16(float d0, float d1, float s, floa
 __device__ __forceinline__ void fold_absmax(float vmax, unsigned* out_max) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0 && vmax > 0.f) {
     const unsigned bits = __float_as_uint(vmax);
     if (bits > __hip_atomic_load(out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_max, bits);
   }
@@ -154,10 +154,11 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
   const long long m0 = (long long)blockIdx.x * BM;
   const int nt0 = blockIdx.y * (BN / 16);
   const int NT = a.Cout / 16;
-  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
-  const float inv = 1.0f / (s_in * a.sw);
 
+  // A tile may span two scans; every ROW is scaled by the power of two that fits its own scan's largest input (a row's K-sum
+  // only sees that scan) and the epilogue divides it out per row: a scan's result does not depend on what else is in the batch
   long long abase[A_SLOTS];
+  float s_row[A_SLOTS];
 #pragma unroll
   for (int r = 0; r < A_SLOTS; ++r) {
     const int slot = tid + r * NTHREADS;
@@ -168,6 +169,7 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
     const int oh = (int)(t2 % a.OH);
     const long long nb = t2 / a.OH;
     abase[r] = ((nb * a.H + (long long)oh * a.SH) * a.W + (long long)ow * a.SW) * a.Cin;
+    s_row[r] = ovn_pow2_scale_for(__uint_as_float(a.in_max[nb]));
   }
 
   f32x4 areg[A_SLOTS][2];
@@ -241,10 +243,10 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
     for (int r = 0; r < A_SLOTS; ++r) {
       const int slot = tid + r * NTHREADS;
       unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-      split_pair_f16(areg[r][0][0], areg[r][0][1], s_in, one, h0, l0);
-      split_pair_f16(areg[r][0][2], areg[r][0][3], s_in, one, h1, l1);
-      split_pair_f16(areg[r][1][0], areg[r][1][1], s_in, one, h2, l2);
-      split_pair_f16(areg[r][1][2], areg[r][1][3], s_in, one, h3, l3);
+      split_pair_f16(areg[r][0][0], areg[r][0][1], s_row[r], one, h0, l0);
+      split_pair_f16(areg[r][0][2], areg[r][0][3], s_row[r], one, h1, l1);
+      split_pair_f16(areg[r][1][0], areg[r][1][1], s_row[r], one, h2, l2);
+      split_pair_f16(areg[r][1][2], areg[r][1][3], s_row[r], one, h3, l3);
       const int off = (slot >> 2) * A_STRIDE + 8 * (slot & 3);
       *reinterpret_cast<u32x4*>(&Ah[buf * ATILE + off]) = (u32x4){h0, h1, h2, h3};
       *reinterpret_cast<u32x4*>(&Al[buf * ATILE + off]) = (u32x4){l0, l1, l2, l3};
@@ -303,26 +305,39 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
     cur ^= 1;
   }
 
-  float vmax = 0.f;
+  // epilogue per m-tile: its 16 rows lie in at most two scans (a scan has at least 16 output rows in every layer this kernel serves;
+  // checked by the launcher)
+  const long long rows_per_scan = (long long)a.OH * a.OW;
 #pragma unroll
-  for (int j = 0; j < WN; ++j) {
-    const int n = (nt0 + wave_n * WN + j) * 16 + lrow;
-    const float bv = a.bias[n];
+  for (int i = 0; i < WM; ++i) {
+    const long long mt0 = m0 + (wave_m * WM + i) * 16;
+    if (mt0 >= a.M) continue;
+    const long long scan_lo = mt0 / rows_per_scan;
+    float vmax[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    for (int r = 0; r < 4; ++r) {
+      const long long m = mt0 + 4 * g + r;
+      if (m < a.M) {
+        const long long scan = m / rows_per_scan;
+        const float inv = 1.0f / (ovn_pow2_scale_for(__uint_as_float(a.in_max[scan])) * a.sw);
+        float mx = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const long long m = m0 + (wave_m * WM + i) * 16 + 4 * g + r;
-        if (m < a.M) {
-          float v = fmaf(acc[i][j][r], inv, bv);
+        for (int j = 0; j < WN; ++j) {
+          const int n = (nt0 + wave_n * WN + j) * 16 + lrow;
+          float v = fmaf(acc[i][j][r], inv, a.bias[n]);
           if (a.relu) v = fmaxf(v, 0.0f);
           a.out[m * a.Cout + n] = v;
-          vmax = fmaxf(vmax, fabsf(v));
+          mx = fmaxf(mx, fabsf(v));
         }
+        if (scan == scan_lo) vmax[0] = fmaxf(vmax[0], mx);
+        else vmax[1] = fmaxf(vmax[1], mx);
       }
     }
+    if (a.out_max) {
+      fold_absmax(vmax[0], a.out_max + scan_lo);
+      fold_absmax(vmax[1], a.out_max + scan_lo + 1);   // zero unless the tile straddles a scan boundary: no atomic then
+    }
   }
-  if (a.out_max) fold_absmax(vmax, a.out_max);
 }
 
 // static LDS (<= 64 KB): the common tiles
@@ -344,116 +359,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_mfma_f16x3_dyn_ke
   conv_mfma_f16x3_body<WM, WN, WAVES_M, WAVES_N, VEC4>(a, one, reinterpret_cast<_Float16*>(conv_smem),
                                                        reinterpret_cast<_Float16*>(conv_smem) + 2 * BM * A_STRIDE,
                                                        conv_smem + 4 * BM * A_STRIDE * sizeof(_Float16));
-}
-
-// Split-K variant for launches with few output rows (a single scan's leg: M = 360..2490 rows against K up to 2304).
-// The tiled kernel above then runs a handful of workgroups through 36-72 serial K chunks, each a
-// load -> split -> LDS -> barrier -> MFMA round trip (~1 us): latency bound.  Here a workgroup owns 16 output rows x all
-// NT*16 output channels and its NS waves each take every NS-th K chunk: operands go global -> registers -> MFMA with
-// a one-chunk register prefetch, no LDS and no barrier in the loop; the NS partial tiles are summed through LDS in
-// a fixed order at the end (deterministic).  Needs Cin % 8 == 0 (a lane's 8 consecutive k are 8 consecutive channels).
-template <int NT, int NS>
-__global__ __launch_bounds__(64 * NS) void conv_splitk_f16x3_kernel(ConvArgsB a, float one) {
-  constexpr int N = NT * 16;
-  __shared__ float red[NS][16][N];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int lrow = lane & 15;
-  const int g = lane >> 4;
-
-  const long long m0 = (long long)blockIdx.x * 16;
-  long long m = m0 + lrow;
-  if (m >= a.M) m = a.M - 1;
-  const int ow = (int)(m % a.OW);
-  const long long t2 = m / a.OW;
-  const int oh = (int)(t2 % a.OH);
-  const long long nb = t2 / a.OH;
-  const float* arow = a.in + ((nb * a.H + (long long)oh * a.SH) * a.W + (long long)ow * a.SW) * a.Cin;
-
-  f32x4 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
-  const float inv = 1.0f / (s_in * a.sw);
-  f32x4 av[2][2];
-  f16x8 bv[2][NT][2];
-  auto load = [&](int kc, int buf) {
-    const int k = kc * KC + 8 * g;
-    av[buf][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    av[buf][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (k < a.K) {
-      const int kh = k / a.KWC;
-      const int x = k - kh * a.KWC;
-      const float* p = arow + (long long)kh * a.rowstride + x;
-      av[buf][0] = *reinterpret_cast<const f32x4*>(p);
-      av[buf][1] = *reinterpret_cast<const f32x4*>(p + 4);
-    }
-    const _Float16* wsrc = a.wp + (long long)kc * NT * 1024 + lane * 8;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      bv[buf][j][0] = *reinterpret_cast<const f16x8*>(wsrc + j * 1024);
-      bv[buf][j][1] = *reinterpret_cast<const f16x8*>(wsrc + j * 1024 + 512);
-    }
-  };
-  auto compute = [&](int buf) {
-    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
-    split_pair_f16(av[buf][0][0], av[buf][0][1], s_in, one, h0, l0);
-    split_pair_f16(av[buf][0][2], av[buf][0][3], s_in, one, h1, l1);
-    split_pair_f16(av[buf][1][0], av[buf][1][1], s_in, one, h2, l2);
-    split_pair_f16(av[buf][1][2], av[buf][1][3], s_in, one, h3, l3);
-    const f16x8 ah = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});
-    const f16x8 al = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bv[buf][j][0], acc[j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bv[buf][j][0], acc[j], 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bv[buf][j][1], acc[j], 0, 0, 0);
-  };
-
-  // chunks wave, wave + NS, ... ; two per iteration so that the register buffers are addressed statically
-  int kc = wave;
-  if (kc < a.nkc) load(kc, 0);
-  while (kc < a.nkc) {
-    if (kc + NS < a.nkc) load(kc + NS, 1);
-    compute(0);
-    kc += NS;
-    if (kc >= a.nkc) break;
-    if (kc + NS < a.nkc) load(kc + NS, 0);
-    compute(1);
-    kc += NS;
-  }
-
-  // C/D layout: lane holds column lrow of n-tile j, rows 4g..4g+3
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][4 * g + r][16 * j + lrow] = acc[j][r];
-  __syncthreads();
-  float vmax = 0.f;
-  for (int e = tid; e < 16 * N; e += 64 * NS) {
-    const int row = e / N;
-    const int n = e - row * N;
-    float v = red[0][row][n];
-#pragma unroll
-    for (int w = 1; w < NS; ++w) v += red[w][row][n];
-    v = fmaf(v, inv, a.bias[n]);
-    if (a.relu) v = fmaxf(v, 0.0f);
-    if (m0 + row < a.M) {
-      a.out[(m0 + row) * a.Cout + n] = v;
-      vmax = fmaxf(vmax, fabsf(v));
-    }
-  }
-  if (a.out_max) fold_absmax(vmax, a.out_max);
-}
-
-template <int NT, int NS>
-int launch_conv_splitk(const ConvArgsB& a, hipStream_t stream) {
-  hipLaunchKernelGGL((conv_splitk_f16x3_kernel<NT, NS>), dim3((unsigned)((a.M + 15) / 16)), dim3(64 * NS), 0, stream, a, 1.0f);
-  OVN_HIP_CHECK(hipGetLastError());
-  return OVN_OK;
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N>
@@ -511,31 +416,35 @@ int ovn_conv_prepare_f16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t
   return OVN_OK;
 }
 
-// |x| maximum of n floats folded into *out_max (float bits; zero it first)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out_max) {
+// out_max[scan] = max |x| over the `per_scan` floats of every scan (float bits; zero the words first).  Grid (blocks, scans).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long per_scan, unsigned* __restrict__ out_max) {
+  const float* xs = x + (long long)blockIdx.y * per_scan;
   float m = 0.f;
-  const long long n4 = n >> 2;
-  const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const f32x4 v = x4[i];
-    m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+  if ((reinterpret_cast<uintptr_t>(xs) & 15) == 0) {
+    const long long n4 = per_scan >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+      const f32x4 v = x4[i];
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (per_scan & 3)) m = fmaxf(m, fabsf(xs[4 * n4 + threadIdx.x]));
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_scan; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(xs[i]));
   }
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[4 * n4 + threadIdx.x]));
-  fold_absmax(m, out_max);
+  fold_absmax(m, out_max + blockIdx.y);
 }
 
-int ovn_absmax_forward(const float* x, long long n, unsigned* out_max, hipStream_t stream) {
-  OVN_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, OVN_ERR_ARG, "ovn_absmax_forward: input must be 16-byte aligned");
-  const long long want = (n / 4 + 255) / 256;
-  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-  hipLaunchKernelGGL(absmax_kernel, dim3(grid), dim3(256), 0, stream, x, n, out_max);
+int ovn_absmax_forward(const float* x, int n_scans, long long per_scan, unsigned* out_max, hipStream_t stream) {
+  if (n_scans <= 0 || per_scan <= 0) return OVN_OK;
+  const long long want = (per_scan / 4 + 255) / 256;
+  const unsigned grid = (unsigned)(want < 1 ? 1 : (want > 64 ? 64 : want));
+  hipLaunchKernelGGL(absmax_kernel, dim3(grid, (unsigned)n_scans), dim3(256), 0, stream, x, per_scan, out_max);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
 
 int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh_out,
-                           int* ow_out, const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows,
-                           long long call_nb) {
+                           int* ow_out, const unsigned* in_max, unsigned* out_max, hipStream_t stream) {
   OVN_REQUIRE(L.wp_h != nullptr && L.bias != nullptr, OVN_ERR_STATE, "layer %s has no f16x3 weights", L.name.c_str());
   OVN_REQUIRE(in_max != nullptr, OVN_ERR_ARG, "layer %s: f16x3 arithmetic needs the input maximum", L.name.c_str());
   OVN_REQUIRE(h >= L.kh && w >= L.kw, OVN_ERR_ARG, "layer %s: input %dx%d smaller than kernel", L.name.c_str(), h, w);
@@ -564,24 +473,14 @@ int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h
   if (oh_out) *oh_out = a.OH;
   if (ow_out) *ow_out = a.OW;
   if (a.M == 0) return OVN_OK;
-  {  // many scans of s_conv3 / s_conv3a: input strip resident in LDS (conv_strip.hip)
-    if (!few_rows) {
-      const int took = ovn_conv_strip_try(L, in, nb, call_nb > nb ? call_nb : nb, h, w, out, in_max, out_max, stream);
-      if (took < 0) return -took;
-      if (took > 0) return OVN_OK;
-    }
+  {  // the leg's layer shapes: input strip resident in LDS (conv_strip.hip), for EVERY call size -- same per-accumulator summation
+     // order as the generic kernel below and per-scan scales in both, so which of the two runs never shows in the result
+    const int took = ovn_conv_strip_try(L, in, nb, nb, h, w, out, in_max, out_max, stream);
+    if (took < 0) return -took;
+    if (took > 0) return OVN_OK;
   }
+  OVN_REQUIRE((long long)a.OH * a.OW >= 16, OVN_ERR_ARG, "layer %s: fewer than 16 output positions per image", L.name.c_str());
   const bool vec4 = (L.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
-  // few output rows (single-scan leg): split K across the waves of 16-row workgroups instead of tiling M
-  static const int splitk = getenv("OVN_CONV_SPLITK") ? atoi(getenv("OVN_CONV_SPLITK")) : 1;
-  if (splitk && few_rows && vec4 && L.cin % 8 == 0 && a.M <= 4096 && a.nkc >= 8) {
-    switch (L.cout) {
-      case 32: return launch_conv_splitk<2, 8>(a, stream);
-      case 64: return launch_conv_splitk<4, 8>(a, stream);
-      case 128: return launch_conv_splitk<8, 8>(a, stream);
-      default: break;
-    }
-  }
   switch (L.cout) {
     case 16: return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);
     case 32: return launch_conv_b<2, 2, 4, 1>(a, vec4, stream);

@@ -30,8 +30,8 @@ struct StripArgs {
   const _Float16* wp;
   const float* bias;
   float* out;
-  const unsigned* in_max;   // float bits of max |input| of the call (device)
-  unsigned* out_max;        // NULL or where max |output| is folded
+  const unsigned* in_max;   // [scan] float bits of max |input| of every scan of the launch (device)
+  unsigned* out_max;        // NULL or [scan]: where max |output| of every scan is folded
   float sw, one;            // weight scale; 1.0f (keeps v_fma_mix selectable, see conv_f16x3.hip)
   int H, W, OH, OW, XT;   // input rows / cols, output rows / cols, x tiles per output row
 };
@@ -57,8 +57,6 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
   _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
   _Float16* sl = sh + C::NPL * PLANE;
-  const float s_in = ovn_pow2_scale_for(__uint_as_float(*a.in_max));
-  const float inv = 1.0f / (s_in * a.sw);
   const float one = a.one;
 
   const int tid = threadIdx.x;
@@ -77,6 +75,10 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   const int x0 = xt * TW;
   const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;           // valid output pixels of this tile
   const int pixv = (a.W - x0 < PIX) ? a.W - x0 : PIX;         // valid input pixels per strip row
+  // power-of-two scale from the largest |input| of THIS scan (left by the producing layer): a scan's result does not depend on
+  // what else is in the batch
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[b]));
+  const float inv = 1.0f / (s_in * a.sw);
 
   // ---- strip -> LDS, split once ----
   {
@@ -205,7 +207,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
     const unsigned bits = __float_as_uint(vmax);   // skip the atomic unless it raises the word (see fold_absmax, conv_f16x3.hip)
-    if (lane == 0 && bits > __hip_atomic_load(a.out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max, bits);
+    if (lane == 0 && bits > __hip_atomic_load(a.out_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max + b, bits);
   }
 }
 
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
   _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
   _Float16* sl = sh + KHS * PIXA * CIN;
-  float s_in = OWN ? 1.0f : ovn_pow2_scale_for(__uint_as_float(*a.in_max));
+  float s_in = 1.0f;   // OWN: from the strip itself, below; else from the scan's input maximum once the scan index is known
   const float one = a.one;
 
   const int tid = threadIdx.x;
@@ -264,6 +266,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   const int ohb = (a.OH + ROWS - 1) / ROWS;                    // row blocks per image
   const int oy = ROWS * (bid % ohb);                           // first output row of the block
   const int b = bid / ohb;
+  if (!OWN) s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[b]));
   const int x0 = xt * TW;                                      // first output pixel of the tile
   const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;
   const int px0 = SW * x0;                                     // first input pixel of the strip
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
     const unsigned bits = __float_as_uint(vmax);
-    if (lane == 0 && bits > __hip_atomic_load(a.out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max, bits);
+    if (lane == 0 && bits > __hip_atomic_load(a.out_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max + b, bits);
   }
 }
 
@@ -410,8 +413,7 @@ int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long
   a.OW = (w - KW) / SW + 1;
   a.XT = (a.OW + TW - 1) / TW;
   const long long wgs = (long long)nb * ((a.OH + ROWS - 1) / ROWS) * a.XT;
-  *took = call_nb * a.OH * a.XT >= 384;
-  if (!*took) return OVN_OK;
+  *took = true;   // every call size takes this kernel: the arithmetic of a scan must not depend on the size of its batch
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS, OWN>), C::LDS_BYTES);
   if (rc) return rc;
   hipLaunchKernelGGL((conv_strip_small_kernel<CIN, KH, SH, KW, SW, TW, NT, ROWS, OWN>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
@@ -438,10 +440,7 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_
   a.OW = w - KW + 1;
   a.XT = (a.OW + TW - 1) / TW;
   const long long wgs = (long long)nb * a.OH * a.XT;
-  // too few workgroups to fill the chip: the generic kernel tiles finer.  Decided on the scans of the whole CALL, so that every
-  // slice of a call (and with it every scan) takes the same kernel
-  *took = call_nb * a.OH * a.XT >= 384;
-  if (!*took) return OVN_OK;
+  *took = true;   // every call size takes this kernel (one scan: OH x XT workgroups, still faster than the generic kernel's serial K walk)
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), C::LDS_BYTES);
   if (rc) return rc;
   hipLaunchKernelGGL((conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
@@ -458,8 +457,8 @@ static int pad_rows(int ow, int tw) { return (ow + tw - 1) / tw * tw - ow; }   /
 bool ovn_conv_strip_own_scale(const OvnConvLayer& L, long long call_nb, int h, int w) {
   if (!(L.relu && L.wp_h != nullptr && L.wp_h16 != nullptr) || h < L.kh || w < L.kw) return false;
   if (!(L.kh == 5 && L.kw == 15 && L.cin == 4 && L.cout == 16 && L.sh == 2 && L.sw == 2)) return false;
-  const int oh = (h - 5) / 2 + 1, ow = (w - 15) / 2 + 1;
-  return call_nb * oh * ((ow + 223) / 224) >= 384;
+  (void)call_nb;   // the choice must not depend on the size of the call
+  return true;
 }
 
 // Returns 1 when the layer / call was taken (result in out), 0 when the caller should use the generic kernel, < 0 on error.

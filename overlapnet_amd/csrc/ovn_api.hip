@@ -253,25 +253,28 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
     }
   }
   // process the batch in slices so the scratch stays bounded (2 x slice x 850 KB at C=4)
-  const int64_t slice = 256;
+  const int64_t slice = OVN_LEG_SLICE;
   const size_t buf_bytes = ((size_t)slice * max_act * sizeof(float) + 255) & ~(size_t)255;
   int rc = ovn_ws_reserve(ctx, 2 * buf_bytes, stream);
   if (rc) return rc;
   float* buf[2] = {reinterpret_cast<float*>(ctx->ws), reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + buf_bytes)};
   const size_t in_elems = (size_t)ctx->in_h * ctx->in_w * ctx->in_c;
   OVN_REQUIRE(ctx->leg.size() + 1 <= OVN_ACTMAX_SLOTS, OVN_ERR_STATE, "ovn_leg: too many leg layers");
-  if (ctx->leg_mode != 0 && !ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, OVN_ACTMAX_SLOTS * sizeof(unsigned)));
+  const size_t actmax_bytes = (size_t)OVN_ACTMAX_SLOTS * OVN_LEG_SLICE * sizeof(unsigned);
+  if (ctx->leg_mode != 0 && !ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, actmax_bytes));
   for (int64_t s0 = 0; s0 < n; s0 += slice) {
     const int nb = (int)((n - s0 < slice) ? (n - s0) : slice);
     const float* cur = images_dev + (size_t)s0 * in_elems;
     int h = ctx->in_h, w = ctx->in_w;
-    if (ctx->leg_mode != 0) {   // f16x3: slot li = max |input of layer li| of this slice, folded by the producing kernel
-      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, OVN_ACTMAX_SLOTS * sizeof(unsigned), stream));
-      // (skipped when the first layer's kernel takes the maximum of each input strip itself)
-      const bool own = n > 8 && (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_conv_strip_own_scale(ctx->leg[0], n, h, w);
+    if (ctx->leg_mode != 0) {
+      // f16x3: word [li][scan] = max |input of layer li| of that scan, folded by the kernel that produces it.  Scales are per scan
+      // and every call size runs the same kernels, so a scan's feature volume does not depend on the batch it is computed in
+      // (the first layer's kernel at C = 4 and the fused tail take the maximum of their own strip / tile instead)
+      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, (ctx->leg.size() + 1) * OVN_LEG_SLICE * sizeof(unsigned), stream));
+      const bool own = (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_conv_strip_own_scale(ctx->leg[0], n, h, w);
       if (!own) {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
-        rc = ovn_absmax_forward(cur, (long long)nb * (long long)in_elems, ctx->actmax, stream);
+        rc = ovn_absmax_forward(cur, nb, (long long)in_elems, ctx->actmax, stream);
         if (rc) return rc;
       }
     }
@@ -279,9 +282,8 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       const bool last = (li + 1 == ctx->leg.size());
       float* dst = last ? features_dev + (size_t)s0 * OVN_FEAT_ELEMS : buf[li & 1];
       int oh = 0, ow = 0;
-      // batched f16x3 calls: the six 1 x KW layers at the end run as one kernel with the activations kept in LDS (the choice is
-      // per call, like the strip kernels', so that every scan of a call takes the same code path)
-      if (ctx->leg_mode != 0 && n > 8 && ovn_leg_tail_matches(ctx, li, h, w)) {
+      // f16x3: the six 1 x KW layers at the end run as one kernel with the activations kept in LDS
+      if (ctx->leg_mode != 0 && ovn_leg_tail_matches(ctx, li, h, w)) {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = ovn_leg_tail_forward(ctx, li, cur, nb, w, features_dev + (size_t)s0 * OVN_FEAT_ELEMS, stream);
         if (rc) return rc;
@@ -290,8 +292,8 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
-                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li,
-                                                           last ? nullptr : ctx->actmax + li + 1, stream, n <= 8, n);
+                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li * OVN_LEG_SLICE,
+                                                           last ? nullptr : ctx->actmax + (li + 1) * OVN_LEG_SLICE, stream);
       }
       if (rc) return rc;
       cur = dst;
@@ -660,12 +662,13 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
   OVN_ON_DEVICE(ctx->device);
   int oh = 0, ow = 0;
   if (ctx->leg_mode == 0) return ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
-  if (!ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, OVN_ACTMAX_SLOTS * sizeof(unsigned)));
-  OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, OVN_ACTMAX_SLOTS * sizeof(unsigned), (hipStream_t)stream));
-  int rc = ovn_absmax_forward(in_dev, (long long)nb * h * w * ctx->leg[layer].cin, ctx->actmax, (hipStream_t)stream);
+  OVN_REQUIRE(nb <= OVN_LEG_SLICE, OVN_ERR_ARG, "ovn_debug_conv: at most %d images per call", OVN_LEG_SLICE);
+  if (!ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, (size_t)OVN_ACTMAX_SLOTS * OVN_LEG_SLICE * sizeof(unsigned)));
+  OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, 2 * (size_t)OVN_LEG_SLICE * sizeof(unsigned), (hipStream_t)stream));
+  int rc = ovn_absmax_forward(in_dev, nb, (long long)h * w * ctx->leg[layer].cin, ctx->actmax, (hipStream_t)stream);
   if (rc) return rc;
-  return ovn_conv_forward_f16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, ctx->actmax, ctx->actmax + 1,
-                                (hipStream_t)stream, nb <= 8);
+  return ovn_conv_forward_f16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, ctx->actmax, ctx->actmax + OVN_LEG_SLICE,
+                                (hipStream_t)stream);
 }
 
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream) {

@@ -69,7 +69,8 @@ constexpr int OVN_C2_OUT = 128;   // c_conv2 filters
 constexpr int OVN_C3_OUT = 256;   // c_conv3 filters
 constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
 constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
-constexpr int OVN_ACTMAX_SLOTS = 32;                           // per-layer activation maxima of a leg call (f16x3 scales)
+constexpr int OVN_ACTMAX_SLOTS = 32;                           // layers with per-scan activation maxima (f16x3 scales)
+constexpr int OVN_LEG_SLICE = 256;                             // scans per pass of ovn_leg over its ping-pong scratch
 constexpr int OVN_SPEC_W = 368;                                 // floats per spectrum row: Re[0..180] | pad | Im at 184.. | pad
 constexpr int OVN_SPEC_ELEMS = OVN_FEAT_C * OVN_SPEC_W;        // 47104 floats = 188,416 B per scan
 
@@ -135,7 +136,7 @@ struct ovn_ctx {
   float* w2sum = nullptr;  // c_conv2 kernel summed over its 15 taps, [64][128]: the right-volume linear term pushed through c_conv2
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
-  unsigned* actmax = nullptr;   // [32] float bits of max |activation| per leg layer input of the running call (f16x3 scales)
+  unsigned* actmax = nullptr;   // [layer][scan of the slice] float bits of max |layer input| of that scan (f16x3 scales)
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = scaled 3-term fp16 split on the fp16 MFMA (default)
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
@@ -150,7 +151,7 @@ struct ovn_ctx {
   int64_t head_chunk = 1024;
   int64_t head_sub = 0;
   int head_streams = 1;
-  int head_yaw_side = 1;
+  int head_yaw_side = 0;   // measured (profiles/r3a_pipeline_matrix.md): no gain from any of the forked forms, the serial order is the default
   bool aux_ready = false;
   hipStream_t aux[2] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
@@ -204,14 +205,12 @@ int ovn_conv_forward(const OvnConvLayer& L, const float* in, int nb, int h, int 
 // conv_f16x3.hip
 // scaled fp16 hi/lo fragments of the layer (wp_h, sw_h); synchronises `stream` (the weight maximum is read back)
 int ovn_conv_prepare_f16x3(OvnConvLayer* L, const float* kernel_dev, hipStream_t stream);
-// in_max: float bits of max |in| over the call (device word, left there by the producer of `in` or by ovn_absmax_forward);
-// out_max: NULL, or a zeroed device word into which max |out| is folded for the next layer.
-// few_rows: the whole call (not just this slice) is a handful of scans -> the split-K kernels may be used; decided by
-// the caller so that every scan of one call takes the same code path
-// call_nb: scans of the whole call (>= nb): the strip kernels are chosen on it, so that every slice takes the same kernels
+// in_max[scan]: float bits of max |in| of every scan of the call (device words, left there by the producer of `in` or by
+// ovn_absmax_forward); out_max: NULL, or zeroed device words [scan] into which max |out| of every scan is folded for the next
+// layer.  Scales are per SCAN and every call size takes the same kernels: a scan's result does not depend on its batch.
 int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, int* oh, int* ow,
-                           const unsigned* in_max, unsigned* out_max, hipStream_t stream, bool few_rows = false, long long call_nb = 0);
-int ovn_absmax_forward(const float* x, long long n, unsigned* out_max, hipStream_t stream);
+                           const unsigned* in_max, unsigned* out_max, hipStream_t stream);
+int ovn_absmax_forward(const float* x, int n_scans, long long per_scan, unsigned* out_max, hipStream_t stream);
 
 // delta_head.hip
 int ovn_delta_prepare_w1(const float* c1_kernel_dev, float** w1p_out, hipStream_t stream);

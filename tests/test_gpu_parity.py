@@ -148,15 +148,39 @@ def test_leg_batch_tail_and_slicing(engines, fixture_images):
     many = torch.from_numpy(np.repeat(imgs[:1], 259, axis=0)).cuda()
     out = e.leg(many)
     assert torch.equal(out, out[:1].expand(259, -1, -1))                     # every batch position identical
-    # calls of <= 8 scans take the split-K kernels for the small layers (different summation order): equal to fp32 rounding
-    d = _rel(one.cpu().numpy(), out[:1].cpu().numpy())
-    assert d < 1e-5, "single-scan vs batched leg differ by %.3g (relative to max)" % d
+    assert torch.equal(one, out[:1])                                         # ... and identical to the scan computed alone
     e.set_leg_precision("f32")
     try:
         assert torch.equal(e.leg(many[:20])[:3], e.leg(many[:1]).expand(3, -1, -1))   # fp32 mode: one kernel, bit-identical
     finally:
         e.set_leg_precision("f16x3")
     assert e.leg(torch.empty((0, 64, 900, 4), device="cuda")).shape == (0, 360, 128)
+
+
+@pytest.mark.parametrize("C", [1, 4, 5])
+def test_leg_result_does_not_depend_on_the_batch(engines, fixture_images, C):
+    """A scan's feature volume depends on that scan alone (reference: `leg.predict_generator`, infer.py:262-265): computed alone, in a
+    batch of 9 next to a 300x-scaled neighbour (which moves every call-wide activation maximum by 8 powers of two), at another
+    position, and in a batch of 259 that crosses the 256-scan slice -- the same bits, in the default (f16x3) arithmetic."""
+    imgs = fixture_images(C)
+    e = engines[C]
+    a = torch.from_numpy(imgs[:1]).cuda()
+    b = torch.from_numpy(imgs[1:2]).cuda()
+    alone = e.leg(a)
+    loud = (300.0 * b).contiguous()
+    quiet = (b / 300.0).contiguous()
+    batch9 = torch.cat([loud, a, b, quiet, loud, b, b, a, quiet]).contiguous()
+    out9 = e.leg(batch9)
+    assert torch.equal(out9[1:2], alone) and torch.equal(out9[7:8], alone)
+    assert torch.equal(out9[2], out9[5]) and torch.equal(out9[0], out9[4]) and torch.equal(out9[3], out9[8])
+    assert torch.equal(out9[2:3], e.leg(b))
+    big = torch.cat([b.expand(257, -1, -1, -1), a, loud]).contiguous()          # scan `a` sits in the second slice
+    outb = e.leg(big)
+    assert outb.shape[0] == 259 and torch.equal(outb[257:258], alone) and torch.equal(outb[258:259], out9[0:1])
+    # the scaled scans are still computed to fp32-equivalent accuracy relative to their own range (their own scales apply)
+    ref = e.leg(b)
+    assert torch.equal(e.leg(loud), out9[0:1])
+    assert torch.isfinite(out9).all() and float(out9[0].abs().max()) > 10 * float(ref.abs().max())
 
 
 PRECISIONS = ("f32", "f16x3")   # arithmetic of the Delta head contractions (ovn_set_head_precision)
