@@ -9,7 +9,7 @@
 // weights are scaled, split and laid out in fragment order when the layer is registered.
 // Scales: the weights' is static (max |W| -> 2^14); the activations' comes from `in_max`, the float bits of the largest
 // |input| of the call, which the PRODUCER of the tensor leaves in device memory (every kernel here folds its outputs into
-// `out_max` with one atomicMax per wave; the first layer's input is scanned by ovn_absmax_forward) -- no host round trip.
+// `out_max` with one atomicMax per workgroup; the first layer's input is scanned by ovn_absmax_forward) -- no host round trip.
 #include <stdlib.h>
 
 #include "ovn_internal.h"
@@ -48,19 +48,6 @@ __device__ __forceinline__ void split_pair_f16(float d0, float d1, float s, floa
   l[1] = (_Float16)__builtin_fmaf(x1, one, -(float)h[1]);
   hi_pk = __builtin_bit_cast(unsigned, h);
   lo_pk = __builtin_bit_cast(unsigned, l);
-}
-
-// max |output| of a wave -> at most one atomicMax (|v| orders like its float bits).  Every wave of a launch targets the SAME
-// word and one address serialises at ~90 atomics/us (100 k waves of s_conv1 = 1.2 ms), so a wave first reads the word
-// (L1-bypassing load; a stale, smaller value only costs a redundant atomic) and skips the atomic unless it would raise it:
-// after the first few waves almost all do.
-__device__ __forceinline__ void fold_absmax(float vmax, unsigned* out_max) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-  if ((threadIdx.x & 63) == 0 && vmax > 0.f) {
-    const unsigned bits = __float_as_uint(vmax);
-    if (bits > __hip_atomic_load(out_max, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out_max, bits);
-  }
 }
 
 // Scaled fp16 hi/lo fragments (f16x3 arithmetic), same fragment order: sw * W = hi + lo, both rounded to nearest.
@@ -169,7 +156,7 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
     const int oh = (int)(t2 % a.OH);
     const long long nb = t2 / a.OH;
     abase[r] = ((nb * a.H + (long long)oh * a.SH) * a.W + (long long)ow * a.SW) * a.Cin;
-    s_row[r] = ovn_pow2_scale_for(__uint_as_float(a.in_max[nb]));
+    s_row[r] = ovn_pow2_scale_for(__uint_as_float(a.in_max[nb * OVN_ACTMAX_STRIDE]));
   }
 
   f32x4 areg[A_SLOTS][2];
@@ -305,21 +292,20 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
     cur ^= 1;
   }
 
-  // epilogue per m-tile: its 16 rows lie in at most two scans (a scan has at least 16 output rows in every layer this kernel serves;
-  // checked by the launcher)
+  // epilogue: the BM rows of the workgroup lie in at most two scans (a scan has at least BM output rows in every layer this kernel
+  // serves; checked by the launcher)
   const long long rows_per_scan = (long long)a.OH * a.OW;
+  const long long scan_lo = m0 / rows_per_scan;
+  float vmax[2] = {0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
     const long long mt0 = m0 + (wave_m * WM + i) * 16;
-    if (mt0 >= a.M) continue;
-    const long long scan_lo = mt0 / rows_per_scan;
-    float vmax[2] = {0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long long m = mt0 + 4 * g + r;
       if (m < a.M) {
         const long long scan = m / rows_per_scan;
-        const float inv = 1.0f / (ovn_pow2_scale_for(__uint_as_float(a.in_max[scan])) * a.sw);
+        const float inv = 1.0f / (ovn_pow2_scale_for(__uint_as_float(a.in_max[scan * OVN_ACTMAX_STRIDE])) * a.sw);
         float mx = 0.f;
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
@@ -333,10 +319,13 @@ __device__ __forceinline__ void conv_mfma_f16x3_body(const ConvArgsB& a, float o
         else vmax[1] = fmaxf(vmax[1], mx);
       }
     }
-    if (a.out_max) {
-      fold_absmax(vmax[0], a.out_max + scan_lo);
-      fold_absmax(vmax[1], a.out_max + scan_lo + 1);   // zero unless the tile straddles a scan boundary: no atomic then
-    }
+  }
+  if (a.out_max) {   // kernel-uniform: every thread takes part in the two workgroup reductions (the LDS tiles are free: the K loop
+                     // ended with a barrier)
+    float* red = reinterpret_cast<float*>(Ah);
+    ovn_fold_absmax_wg(vmax[0], a.out_max + scan_lo * OVN_ACTMAX_STRIDE, red);
+    __syncthreads();
+    ovn_fold_absmax_wg(vmax[1], a.out_max + (scan_lo + 1) * OVN_ACTMAX_STRIDE, red);   // all zero unless the rows straddle two scans: no atomic then
   }
 }
 
@@ -431,7 +420,8 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
   } else {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_scan; i += (long long)gridDim.x * 256) m = fmaxf(m, fabsf(xs[i]));
   }
-  fold_absmax(m, out_max + blockIdx.y);
+  __shared__ float red[16];
+  ovn_fold_absmax_wg(m, out_max + (size_t)blockIdx.y * OVN_ACTMAX_STRIDE, red);
 }
 
 int ovn_absmax_forward(const float* x, int n_scans, long long per_scan, unsigned* out_max, hipStream_t stream) {
@@ -479,7 +469,7 @@ int ovn_conv_forward_f16x3(const OvnConvLayer& L, const float* in, int nb, int h
     if (took < 0) return -took;
     if (took > 0) return OVN_OK;
   }
-  OVN_REQUIRE((long long)a.OH * a.OW >= 16, OVN_ERR_ARG, "layer %s: fewer than 16 output positions per image", L.name.c_str());
+  OVN_REQUIRE((long long)a.OH * a.OW >= 128, OVN_ERR_ARG, "layer %s: fewer than 128 output positions per image", L.name.c_str());
   const bool vec4 = (L.cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
   switch (L.cout) {
     case 16: return launch_conv_b<2, 1, 4, 1>(a, vec4, stream);

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   constexpr int COUT = 16 * NT;
   constexpr int PLANE = C::PLANE, PIX = C::PIX, MTH = C::MTH, CC = C::CC, NK = C::NK;
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
+  __shared__ float wg_red[16];
   _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
   _Float16* sl = sh + C::NPL * PLANE;
   const float one = a.one;
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   const int pixv = (a.W - x0 < PIX) ? a.W - x0 : PIX;         // valid input pixels per strip row
   // power-of-two scale from the largest |input| of THIS scan (left by the producing layer): a scan's result does not depend on
   // what else is in the batch
-  const float s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[b]));
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[(size_t)b * OVN_ACTMAX_STRIDE]));
   const float inv = 1.0f / (s_in * a.sw);
 
   // ---- strip -> LDS, split once ----
@@ -203,12 +204,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
       }
     }
   }
-  if (a.out_max) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    const unsigned bits = __float_as_uint(vmax);   // skip the atomic unless it raises the word (see fold_absmax, conv_f16x3.hip)
-    if (lane == 0 && bits > __hip_atomic_load(a.out_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max + b, bits);
-  }
+  if (a.out_max) ovn_fold_absmax_wg(vmax, a.out_max + (size_t)b * OVN_ACTMAX_STRIDE, wg_red);   // wave-uniform condition: every thread calls it
 }
 
 // ---- few input channels (s_conv1: 4, s_conv2: 16) --------------------------------------------------------------------------
@@ -247,6 +243,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   constexpr int COUT = 16 * NT;
   constexpr int PIXA = C::PIXA, MTH = C::MTH, NK = C::NK, TPS = C::TPS, KSR = C::KSR, KHS = C::KHS, MTR = C::MTR;
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
+  __shared__ float wg_red[16];
   _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
   _Float16* sl = sh + KHS * PIXA * CIN;
   float s_in = 1.0f;   // OWN: from the strip itself, below; else from the scan's input maximum once the scan index is known
@@ -266,7 +263,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
   const int ohb = (a.OH + ROWS - 1) / ROWS;                    // row blocks per image
   const int oy = ROWS * (bid % ohb);                           // first output row of the block
   const int b = bid / ohb;
-  if (!OWN) s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[b]));
+  if (!OWN) s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[(size_t)b * OVN_ACTMAX_STRIDE]));
   const int x0 = xt * TW;                                      // first output pixel of the tile
   const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;
   const int px0 = SW * x0;                                     // first input pixel of the strip
@@ -386,12 +383,7 @@ __global__ __launch_bounds__(512) void conv_strip_small_kernel(StripArgs a) {
       }
     }
   }
-  if (a.out_max) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
-    const unsigned bits = __float_as_uint(vmax);
-    if (lane == 0 && bits > __hip_atomic_load(a.out_max + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.out_max + b, bits);
-  }
+  if (a.out_max) ovn_fold_absmax_wg(vmax, a.out_max + (size_t)b * OVN_ACTMAX_STRIDE, wg_red);   // wave-uniform condition: every thread calls it
 }
 
 template <int CIN, int KH, int SH, int KW, int SW, int TW, int NT, int ROWS, bool OWN>

@@ -260,7 +260,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
   float* buf[2] = {reinterpret_cast<float*>(ctx->ws), reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + buf_bytes)};
   const size_t in_elems = (size_t)ctx->in_h * ctx->in_w * ctx->in_c;
   OVN_REQUIRE(ctx->leg.size() + 1 <= OVN_ACTMAX_SLOTS, OVN_ERR_STATE, "ovn_leg: too many leg layers");
-  const size_t actmax_bytes = (size_t)OVN_ACTMAX_SLOTS * OVN_LEG_SLICE * sizeof(unsigned);
+  const size_t actmax_bytes = (size_t)OVN_ACTMAX_SLOTS * OVN_LEG_SLICE * OVN_ACTMAX_STRIDE * sizeof(unsigned);
   if (ctx->leg_mode != 0 && !ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, actmax_bytes));
   for (int64_t s0 = 0; s0 < n; s0 += slice) {
     const int nb = (int)((n - s0 < slice) ? (n - s0) : slice);
@@ -270,7 +270,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       // f16x3: word [li][scan] = max |input of layer li| of that scan, folded by the kernel that produces it.  Scales are per scan
       // and every call size runs the same kernels, so a scan's feature volume does not depend on the batch it is computed in
       // (the first layer's kernel at C = 4 and the fused tail take the maximum of their own strip / tile instead)
-      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, (ctx->leg.size() + 1) * OVN_LEG_SLICE * sizeof(unsigned), stream));
+      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, (ctx->leg.size() + 1) * OVN_LEG_SLICE * OVN_ACTMAX_STRIDE * sizeof(unsigned), stream));
       const bool own = (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_conv_strip_own_scale(ctx->leg[0], n, h, w);
       if (!own) {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
@@ -292,8 +292,8 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
-                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li * OVN_LEG_SLICE,
-                                                           last ? nullptr : ctx->actmax + (li + 1) * OVN_LEG_SLICE, stream);
+                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li * (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE,
+                                                           last ? nullptr : ctx->actmax + (li + 1) * (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE, stream);
       }
       if (rc) return rc;
       cur = dst;
@@ -663,11 +663,11 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
   int oh = 0, ow = 0;
   if (ctx->leg_mode == 0) return ovn_conv_forward(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, (hipStream_t)stream);
   OVN_REQUIRE(nb <= OVN_LEG_SLICE, OVN_ERR_ARG, "ovn_debug_conv: at most %d images per call", OVN_LEG_SLICE);
-  if (!ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, (size_t)OVN_ACTMAX_SLOTS * OVN_LEG_SLICE * sizeof(unsigned)));
-  OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, 2 * (size_t)OVN_LEG_SLICE * sizeof(unsigned), (hipStream_t)stream));
+  if (!ctx->actmax) OVN_HIP_CHECK(hipMalloc((void**)&ctx->actmax, (size_t)OVN_ACTMAX_SLOTS * OVN_LEG_SLICE * OVN_ACTMAX_STRIDE * sizeof(unsigned)));
+  OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, 2 * (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE * sizeof(unsigned), (hipStream_t)stream));
   int rc = ovn_absmax_forward(in_dev, nb, (long long)h * w * ctx->leg[layer].cin, ctx->actmax, (hipStream_t)stream);
   if (rc) return rc;
-  return ovn_conv_forward_f16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, ctx->actmax, ctx->actmax + OVN_LEG_SLICE,
+  return ovn_conv_forward_f16x3(ctx->leg[layer], in_dev, nb, h, w, out_dev, &oh, &ow, ctx->actmax, ctx->actmax + (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE,
                                 (hipStream_t)stream);
 }
 

@@ -71,6 +71,8 @@ constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
 constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
 constexpr int OVN_ACTMAX_SLOTS = 32;                           // layers with per-scan activation maxima (f16x3 scales)
 constexpr int OVN_LEG_SLICE = 256;                             // scans per pass of ovn_leg over its ping-pong scratch
+constexpr int OVN_ACTMAX_STRIDE = 32;                          // words between the maxima of two scans: every scan's word has its
+                                                               // own 128-byte line (atomics on one line serialise at the memory side)
 constexpr int OVN_SPEC_W = 368;                                 // floats per spectrum row: Re[0..180] | pad | Im at 184.. | pad
 constexpr int OVN_SPEC_ELEMS = OVN_FEAT_C * OVN_SPEC_W;        // 47104 floats = 188,416 B per scan
 
@@ -85,6 +87,26 @@ __host__ __device__ inline float ovn_pow2_scale_for(float m) {
   k = k > 100 ? 100 : (k < -100 ? -100 : k);
   return ldexpf(1.0f, k);
 }
+
+#ifdef __HIPCC__
+// max |value| of a WORKGROUP folded into one device word: wave shuffle reduction, the waves' maxima through `red` (>= 16 floats of
+// LDS that nothing else uses at this point), then at most ONE atomicMax per workgroup (|v| orders like its float bits; skipped when
+// it would not raise the word).  Per-wave atomics on per-scan words cost s_conv1 / s_conv2 +75 % (164 k device-scope atomics per
+// 1025 scans, all waves of a scan arriving at a zeroed word together).  Every thread of the workgroup must call it.
+__device__ __forceinline__ void ovn_fold_absmax_wg(float vmax, unsigned* word, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+  const int nw = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = red[0];
+    for (int w = 1; w < nw; ++w) m = fmaxf(m, red[w]);
+    const unsigned bits = __float_as_uint(m);
+    if (m > 0.f && bits > __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(word, bits);
+  }
+}
+#endif
 
 // static scales / norms of the Delta-head weights (delta_head_f16x3.hip)
 struct OvnHeadScales {
@@ -136,7 +158,7 @@ struct ovn_ctx {
   float* w2sum = nullptr;  // c_conv2 kernel summed over its 15 taps, [64][128]: the right-volume linear term pushed through c_conv2
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
-  unsigned* actmax = nullptr;   // [layer][scan of the slice] float bits of max |layer input| of that scan (f16x3 scales)
+  unsigned* actmax = nullptr;   // [layer][scan of the slice][OVN_ACTMAX_STRIDE] float bits of max |layer input| of that scan (f16x3 scales)
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = scaled 3-term fp16 split on the fp16 MFMA (default)
   float* wd = nullptr;   // dense kernel [123904]
   float* bd = nullptr;   // dense bias [1]
