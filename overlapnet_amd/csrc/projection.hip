@@ -10,6 +10,8 @@
 //   atan2/asin are evaluated in float64 and rounded to float32 (NumPy's float32 versions are only
 //   accurate to ~1 ulp, so bit-equality of the angles is not attainable; the pixel a point lands in
 //   is what matters and that is checked against the reference's shipped fixtures).
+//   The scatter is bound by its atomics (measured, tools/experiments/README.md round 3: 0.9 ms per 1025 clouds, 0.35 ms of it without
+//   them; replacing the float64 atan2 / asin by exact precomputed pixel thresholds changed nothing).
 //   gen_normal_map's per-pixel Python loop (:149-173) becomes one thread per pixel; the vector norm
 //   reproduces np.linalg.norm on a float32 3-vector (float32 products summed in a double -- OpenBLAS
 //   sdot's scalar tail -- then rounded to float32 and square-rooted).
@@ -115,40 +117,103 @@ __global__ void proj_block_scan_kernel(int* __restrict__ block_cnt, int blocks_p
   }
 }
 
-// one thread per pixel: resolve the winner
-__global__ void proj_gather_kernel(const float* __restrict__ points, const long long* __restrict__ offsets,
-                                   const unsigned long long* __restrict__ keys, const int* __restrict__ local_idx,
-                                   const int* __restrict__ block_pref, int blocks_per_scan, long long max_points,
-                                   int HW, int n_scans,
-                                   float* __restrict__ range, float* __restrict__ vertex,
-                                   float* __restrict__ intensity, int32_t* __restrict__ idx) {
-  const long long total = (long long)n_scans * HW;
-  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total;
-       q += (long long)gridDim.x * blockDim.x) {
-    const int scan = (int)(q / HW);
-    const unsigned long long key = keys[q];
-    f32x4 v = {-1.f, -1.f, -1.f, -1.f};
-    float d = -1.f, it = -1.f;
-    int id = -1;
-    if (key != EMPTY_KEY) {
-      const long long p = (long long)(key & 0xFFFFFFFFull);
-      const f32x4 pt = *reinterpret_cast<const f32x4*>(points + (offsets[scan] + p) * 4);
-      d = __uint_as_float((unsigned)(key >> 32));
-      it = pt[3];
-      v = (f32x4){pt[0], pt[1], pt[2], 1.0f};
-      if (idx) id = block_pref[(long long)scan * blocks_per_scan + (int)(p / PB)] + local_idx[(long long)scan * max_points + p];
-    }
-    range[q] = d;
-    *reinterpret_cast<f32x4*>(vertex + q * 4) = v;
-    if (intensity) intensity[q] = it;
-    if (idx) idx[q] = id;
-  }
-}
-
 __device__ __forceinline__ float norm3_like_numpy(float x, float y, float z) {
   // np.linalg.norm(float32[3]) == sqrt(float32(double(x*x) + double(y*y) + double(z*z)))
   const double s = ((double)(x * x) + (double)(y * y)) + (double)(z * z);
   return sqrtf((float)s);
+}
+
+// normal of pixel p from its right (u, wrapped) and lower (v) neighbours, utils.py:149-173; (-1,-1,-1) when undefined
+__device__ __forceinline__ void normal_of(const f32x4& p, const f32x4& u, const f32x4& v, float& nx, float& ny, float& nz) {
+  nx = ny = nz = -1.f;
+  const float ux = u[0] - p[0], uy = u[1] - p[1], uz = u[2] - p[2];
+  const float vx = v[0] - p[0], vy = v[1] - p[1], vz = v[2] - p[2];
+  const float un = norm3_like_numpy(ux, uy, uz);
+  const float vn = norm3_like_numpy(vx, vy, vz);
+  const float ax = vx / vn, ay = vy / vn, az = vz / vn;  // v_norm
+  const float bx = ux / un, by = uy / un, bz = uz / un;  // u_norm
+  const float wx = ay * bz - az * by;                    // np.cross(v_norm, u_norm), utils.py:168
+  const float wy = az * bx - ax * bz;
+  const float wz = ax * by - ay * bx;
+  const float wn = norm3_like_numpy(wx, wy, wz);
+  if (wn > 0.0f) {  // NaN fails the test and the pixel stays -1 (utils.py:170)
+    nx = wx / wn;
+    ny = wy / wn;
+    nz = wz / wn;
+  }
+}
+
+// One thread per pixel: resolve the winner of the pixel and, when normals are wanted, of its right and lower neighbours straight
+// from the key image, and write every requested output ONCE -- the range / vertex images are not materialised unless the caller
+// asked for them (the stacked leg input alone: 8 B of key + three 16-byte point reads in, 4 C bytes out per pixel; the former
+// gather -> range / vertex images -> normal kernel pair moved 2.4 GB more per 1025 scans: 1.17 -> 0.77 ms).
+__global__ __launch_bounds__(256) void proj_resolve_kernel(const float* __restrict__ points, const long long* __restrict__ offsets,
+                                                           const unsigned long long* __restrict__ keys, const int* __restrict__ local_idx,
+                                                           const int* __restrict__ block_pref, int blocks_per_scan, long long max_points,
+                                                           int H, int W, int n_scans, float* __restrict__ range,
+                                                           float* __restrict__ vertex, float* __restrict__ intensity,
+                                                           int32_t* __restrict__ idx, float* __restrict__ normal,
+                                                           float* __restrict__ stacked, int use_depth, int use_normals,
+                                                           int use_intensity, int C) {
+  const int HW = H * W;
+  const long long total = (long long)n_scans * HW;
+  const bool want_n = (normal != nullptr) || (stacked != nullptr && use_normals);
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+    const int scan = (int)(q / HW);
+    const int pix = (int)(q - (long long)scan * HW);
+    const long long sbase = q - pix;
+    const float* pts = points + offsets[scan] * 4;
+    const unsigned long long key = keys[q];
+    f32x4 v = {-1.f, -1.f, -1.f, -1.f};
+    float d = -1.f, it = -1.f, nx = -1.f, ny = -1.f, nz = -1.f;
+    int id = -1;
+    if (key != EMPTY_KEY) {
+      const long long p = (long long)(key & 0xFFFFFFFFull);
+      const f32x4 pt = *reinterpret_cast<const f32x4*>(pts + p * 4);
+      d = __uint_as_float((unsigned)(key >> 32));
+      it = pt[3];
+      v = (f32x4){pt[0], pt[1], pt[2], 1.0f};
+      if (idx) id = block_pref[(long long)scan * blocks_per_scan + (int)(p / PB)] + local_idx[(long long)scan * max_points + p];
+      if (want_n) {
+        const int y = pix / W;
+        const int x = pix - y * W;
+        if (y < H - 1) {
+          const int xr = (x + 1 >= W) ? (x + 1 - W) : (x + 1);  // wrap(), utils.py:178-186
+          const unsigned long long ku = keys[sbase + (long long)y * W + xr];
+          const unsigned long long kv = keys[sbase + (long long)(y + 1) * W + x];
+          if (ku != EMPTY_KEY && kv != EMPTY_KEY) {           // range > 0 at both neighbours (a kept point has depth > 0)
+            const f32x4 pu = *reinterpret_cast<const f32x4*>(pts + (long long)(ku & 0xFFFFFFFFull) * 4);
+            const f32x4 pv = *reinterpret_cast<const f32x4*>(pts + (long long)(kv & 0xFFFFFFFFull) * 4);
+            normal_of(pt, pu, pv, nx, ny, nz);
+          }
+        }
+      }
+    }
+    if (range) range[q] = d;
+    if (vertex) *reinterpret_cast<f32x4*>(vertex + q * 4) = v;
+    if (intensity) intensity[q] = it;
+    if (idx) idx[q] = id;
+    if (normal) {
+      normal[q * 3 + 0] = nx;
+      normal[q * 3 + 1] = ny;
+      normal[q * 3 + 2] = nz;
+    }
+    if (stacked) {
+      float* o = stacked + q * C;
+      if (C == 4 && use_depth && use_normals) {
+        *reinterpret_cast<f32x4*>(o) = (f32x4){d, nx, ny, nz};
+      } else {
+        int c = 0;
+        if (use_depth) o[c++] = d;
+        if (use_normals) {
+          o[c++] = nx;
+          o[c++] = ny;
+          o[c++] = nz;
+        }
+        if (use_intensity) o[c++] = it;
+      }
+    }
+  }
 }
 
 // one thread per pixel: normal (utils.py:149-173) + the stacked leg input
@@ -235,11 +300,8 @@ int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offset
   const long long HW = (long long)H * W;
   const long long npix = HW * n_scans;
   const int blocks_per_scan = (int)((max_points + PB - 1) / PB) > 0 ? (int)((max_points + PB - 1) / PB) : 1;
-  const bool need_vertex = (vertex == nullptr);
-  const bool need_range = (range == nullptr);
-  const bool need_int = (intensity == nullptr) && (stacked && use_intensity);
 
-  // scratch carve-up (all 16-byte aligned)
+  // scratch carve-up (all 16-byte aligned): the key image, and for the index image the kept-point numbering
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     size_t o = off;
@@ -249,18 +311,11 @@ int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offset
   const size_t o_keys = carve((size_t)npix * 8);
   const size_t o_lidx = idx ? carve((size_t)n_scans * (size_t)max_points * 4 + 16) : 0;
   const size_t o_bcnt = idx ? carve((size_t)n_scans * blocks_per_scan * 4) : 0;
-  const size_t o_rng = need_range ? carve((size_t)npix * 4) : 0;
-  const size_t o_vtx = need_vertex ? carve((size_t)npix * 16) : 0;
-  const size_t o_int = need_int ? carve((size_t)npix * 4) : 0;
   int rc = ovn_ws_reserve(ctx, off, stream);
   if (rc) return rc;
   char* ws = static_cast<char*>(ctx->ws);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(ws + o_keys);
   int* block_cnt = idx ? reinterpret_cast<int*>(ws + o_bcnt) : nullptr;
-  float* rng = need_range ? reinterpret_cast<float*>(ws + o_rng) : range;
-  float* vtx = need_vertex ? reinterpret_cast<float*>(ws + o_vtx) : vertex;
-  float* itn = need_int ? reinterpret_cast<float*>(ws + o_int) : intensity;
-
   // local_idx is indexed [scan][point]: n_scans * max_points ints
   int* local_idx = idx ? reinterpret_cast<int*>(ws + o_lidx) : nullptr;
 
@@ -271,13 +326,10 @@ int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offset
                        (long long)max_points);
     if (idx) hipLaunchKernelGGL(proj_block_scan_kernel, dim3(n_scans), dim3(64), 0, stream, block_cnt, blocks_per_scan);
   }
-  const int gblocks = (int)((npix + 255) / 256 < 4096 ? (npix + 255) / 256 : 4096);
-  hipLaunchKernelGGL(proj_gather_kernel, dim3(gblocks), dim3(256), 0, stream, points,
-                     reinterpret_cast<const long long*>(offsets), keys, local_idx, block_cnt, blocks_per_scan,
-                     (long long)max_points, (int)HW, n_scans, rng, vtx, itn, idx);
-  if (normal || stacked)
-    hipLaunchKernelGGL(proj_normal_kernel, dim3(gblocks), dim3(256), 0, stream, rng, vtx, itn, H, W, n_scans, normal,
-                       stacked, use_depth, use_normals, use_intensity, C);
+  const int gblocks = (int)((npix + 255) / 256 < 8192 ? (npix + 255) / 256 : 8192);
+  hipLaunchKernelGGL(proj_resolve_kernel, dim3(gblocks), dim3(256), 0, stream, points, reinterpret_cast<const long long*>(offsets),
+                     keys, local_idx, block_cnt, blocks_per_scan, (long long)max_points, H, W, n_scans, range, vertex, intensity, idx,
+                     normal, stacked, use_depth, use_normals, use_intensity, C);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
