@@ -4,6 +4,10 @@ Restates what the reference's demo3 does around `Infer.infer_multiple` (demo/dem
 frames older than `inactive_time_thres`, travelled further than `inactive_dist_thres` ago, and inside the
 n-sigma covariance ellipse around the current pose; the loop closure is the candidate with the largest overlap
 if that exceeds `overlap_thres`.  Animation / plotting are out of scope.
+
+Pinned on the reference's own code: tests/golden/lcd_gating.npz holds, frame by frame, the ellipse, the candidate list and the
+reported loop closure produced by `AnimatedLCD.get_cov_ellipse` / `get_predictions` (imported unmodified by
+tests/golden/make_lcd_golden.py) for three synthetic trajectories; tests/test_host_logic.py requires equality.
 """
 from __future__ import annotations
 

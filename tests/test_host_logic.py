@@ -146,3 +146,34 @@ def test_pair_reader_both_layouts_and_test_run(tmp_path):
     m = np.load(str(tmp_path / "res" / "validation_results.npz"))["arr_0"]
     assert m.shape == (5, 4) and np.array_equal(m[:, 3], np.arange(5) * 3) and np.allclose(m[:, 2], np.linspace(0.1, 0.9, 5))
     assert st["n"] == 5 and abs(st["overlap_mae"] - np.mean(np.abs(np.linspace(0.1, 0.9, 5) - arr[:5, 2]))) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["out_and_back", "figure_eight", "random_walk"])
+def test_loop_closure_gating_against_reference_golden(name):
+    """PINNED on the reference's own code: tests/golden/lcd_gating.npz was produced by running `AnimatedLCD.get_cov_ellipse` /
+    `get_predictions` of demo/demo3_lcd.py:85-140 (imported unmodified, tests/golden/make_lcd_golden.py) over synthetic
+    trajectories with a recorder in place of the network.  Frame by frame: the same ellipse, the same candidate list handed to
+    `infer_multiple`, the same reported loop closure."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_lcd_golden", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                                                  "make_lcd_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                       # only its RecorderInfer / fake_overlap helpers; no reference import
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lcd_gating.npz")) as z:
+        g = {k[len(name) + 1:]: z[k] for k in z.files if k.startswith(name + "_")}
+    xy, cov = g["xy"], g["cov"]
+    tl = lcd.travelled_distances(xy)
+    rec = gen.RecorderInfer()
+    for idx in range(len(xy)):
+        ell = lcd.covariance_ellipse(cov[idx], nstd=3.0)
+        np.testing.assert_allclose(ell, g["ellipse"][idx], rtol=1e-12, atol=1e-12)
+        ref = lcd.gate_candidates(idx, xy, tl, ell)
+        want = g["refs"][g["refs_off"][idx]:g["refs_off"][idx + 1]]
+        assert np.array_equal(ref, want), (name, idx)
+        got = lcd.detect(rec, idx, xy, tl, ell)
+        assert rec.calls[-1] == (idx, list(want))      # the frame is ALWAYS fed to infer_multiple (it caches the feature volume)
+        assert (-2 if got is None else got[0]) == g["result"][idx], (name, idx, got)
+        if got is not None:
+            k = list(want).index(got[0])
+            assert got[1] == float(gen.fake_overlap(idx, want)[k]) and got[2] == int(gen.fake_yaw(idx, want)[k])
+    assert len(rec.calls) == len(xy) and int(np.sum(g["result"] >= 0)) > 50
