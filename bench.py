@@ -210,6 +210,7 @@ def main():
     ap.add_argument("--corr", default="spectral", choices=["spectral", "direct"],
                     help="correlation head: spectral form on cached candidate spectra (default) or direct Gram form")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (path check)")
+    ap.add_argument("--no-delta-cache", action="store_true", help="warm sweep without the candidates' Delta cache rows (round-2 behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32_mode / cold / fullstack / corr_head sub-records")
     ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against a LIVE fp64 oracle when no committed "
@@ -321,6 +322,7 @@ def main():
 
     spectral = args.corr == "spectral"
     cand_spec = eng.spectrum(cands) if spectral else None          # cached per candidate, like its feature volume
+    cand_dc = eng.delta_cache(cands) if (spectral and args.head_precision == "f16x3" and not args.no_delta_cache) else None
     query_spec = torch.empty((1, 128, eng.SPEC_W), dtype=torch.float32, device=dev)
     all_fv = None
     torch.cuda.synchronize()
@@ -334,7 +336,7 @@ def main():
         eng.leg(query_img, out=query_fv)
         if spectral:
             eng.spectrum(query_fv, out=query_spec)
-            return finish(eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec))
+            return finish(eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec, dcache_l=cand_dc))
         return finish(eng.heads(cands, query_fv))
 
     def make_step_cold(raw):
@@ -347,6 +349,7 @@ def main():
             cf, qf = all_fv[:P], all_fv[P:]
             if spectral:
                 sp = eng.spectrum(all_fv)
+                # (no Delta cache here: its rows pay when a candidate meets many queries; built and used once they only move work)
                 return finish(eng.heads(cf, qf, spec_l=sp[:P], spec_r=sp[P:]))
             return finish(eng.heads(cf, qf))
         return step_cold
@@ -526,7 +529,8 @@ def main():
             def q_step():
                 eng.leg(query_img, out=query_fv)
                 eng.spectrum(query_fv, out=query_spec)
-                r = eng.heads(cands[:n_c], query_fv, spec_l=cand_spec[:n_c], spec_r=query_spec)
+                r = eng.heads(cands[:n_c], query_fv, spec_l=cand_spec[:n_c], spec_r=query_spec,
+                              dcache_l=cand_dc[:n_c] if cand_dc is not None else None)
                 return decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3))
             for _ in range(5):
                 q_step()

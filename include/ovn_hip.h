@@ -39,7 +39,7 @@ typedef struct ovn_ctx ovn_ctx;
 #define OVN_ERR_STATE 3    /* call order (weights missing ...)  */
 
 /* ABI version of this header; bumped on any signature change. */
-#define OVN_ABI_VERSION 1
+#define OVN_ABI_VERSION 2
 int ovn_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -113,14 +113,25 @@ int ovn_spectrum(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* spectra
 int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l_dev, const int32_t* lidx_dev, const float* spec_r_dev,
                            const int32_t* ridx_dev, int64_t n, int32_t* yaw_dev, float* corr_dev, void* stream);
 
-/* Both heads of a sweep whose candidates have their spectra cached next to their feature volumes: what `Infer.infer_multiple`
- * runs per query.  Same outputs and indexing as ovn_heads (one index array addresses both the feature and the spectrum pool);
- * the Delta head reads the feature volumes, the yaw head the spectra (ONE launch for the whole sweep).  With
+/* Delta cache: everything of a pair's Delta-head preparation that depends on the LEFT volume (the candidate of a sweep) alone --
+ * its feature volume re-written as the packed hi/lo fp16 words the contraction kernel streams (at the candidate's own power-of-two
+ * scale), its linear term pushed through c_conv2 (TT + b2) and its value range.  OVN_DELTA_CACHE_ELEMS floats (196,864 B) per
+ * volume, cached next to the feature volume and the spectrum (the reference caches per-candidate state too: infer.py:184-185).
+ * A row is used by ovn_heads_spectral for a pair whenever neither volume has a negative value and the query's largest value is
+ * below the candidate's next power of two; every other pair is prepared in scratch as without a cache -- same bits either way.
+ * Valid for the head weights registered when it was built (f16x3 head mode; the fp32 mode ignores it). */
+#define OVN_DELTA_CACHE_ELEMS 49216
+int ovn_delta_cache(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* cache_dev, void* stream);
+
+/* Both heads of a sweep whose candidates have their spectra (and optionally their Delta cache rows, dcache_l_dev, may be NULL) cached
+ * next to their feature volumes: what `Infer.infer_multiple` runs per query.  Same outputs and indexing as ovn_heads (one index
+ * array addresses the feature, spectrum and Delta-cache pools alike); the Delta head reads the feature volumes / cache rows, the yaw
+ * head the spectra (ONE launch for the whole sweep).  The Delta cache is used in the 1-vs-N form (ridx_dev == NULL).  With
  * ovn_set_head_pipeline the call can fork the independent kernel chains over context-owned side streams; it joins them back into
  * `stream` with events before it returns: to the caller everything is ordered as if enqueued on `stream`.
  * Replaces `head.predict_generator` + post-processing for 1-vs-N sweeps (infer.py:188-198). */
-int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec_l_dev, const int32_t* lidx_dev,
-                       const float* feats_r_dev, const float* spec_r_dev, const int32_t* ridx_dev, int64_t n,
+int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec_l_dev, const float* dcache_l_dev,
+                       const int32_t* lidx_dev, const float* feats_r_dev, const float* spec_r_dev, const int32_t* ridx_dev, int64_t n,
                        float* overlap_dev, int32_t* yaw_dev, float* logit_dev, float* corr_dev, void* stream);
 
 /* Launch structure of the head calls (the reference's counterpart is `batch_size`, network.yml:41, which sets how many pairs one

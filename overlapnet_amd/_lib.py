@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libovn_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -34,7 +34,8 @@ SIGNATURES = {
     "ovn_corr_head": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "ovn_spectrum": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "ovn_corr_head_spectral": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    "ovn_heads_spectral": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "ovn_heads_spectral": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "ovn_delta_cache": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "ovn_set_head_pipeline": (C.c_int, [_vp, C.c_int64, C.c_int64, C.c_int, C.c_int]),
     "ovn_get_head_pipeline": (C.c_int, [_vp, _i64p, _i64p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ovn_best_match": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_float, C.c_int64, _vp, _vp]),

@@ -266,6 +266,26 @@ constexpr size_t O1RAW_ELEMS = (size_t)G * FW * O1; // per pair: 552,960 floats 
 constexpr int C2_TILE_ROWS = 192;                   // rows (jb % 8, ib) of one c_conv2 workgroup; o1raw is stored [tile][k-step][row][32]
 constexpr size_t PREP_SPLIT_LDS = 2 * (size_t)G * TT_STRIDE * sizeof(_Float16) + ((size_t)G * O1 + 2 * NWAVE) * sizeof(float) + (size_t)FC * O1 * 2 * sizeof(_Float16);
 
+// Where the contraction and c_conv2 kernels find a pair's operands: the per-pair scratch filled by the prepare kernel, or -- for a
+// sweep over candidates with a Delta cache (ovn_delta_cache) -- the candidate's cached row and the query's shared operands.
+struct DeltaDesc {
+  const unsigned* pl;   // packed L words [s(4)][i(360)][g(4)][8]
+  const unsigned* pr;   // packed R words [jb(24)][s(4)][dj(15)][g(4)][8]
+  const float* tt;      // TT + b2 [24][128]
+  const float* aa;      // AA [24][128]
+};
+static_assert(sizeof(DeltaDesc) == 32, "DeltaDesc is read as two 16-byte words");
+
+// Delta cache row of one candidate (OVN_DELTA_CACHE_ELEMS floats): packed words at the candidate's OWN scale (valid for a pair
+// whenever the query's largest value does not reach the next power of two and nothing is negative), TT + b2, {max, min}.
+constexpr int DC_PL = 0;                             // [46080] words
+constexpr int DC_TT = OVN_FEAT_ELEMS;                // [24 * 128] floats
+constexpr int DC_META = DC_TT + G * O2;              // {max L, min L, 0, 0}
+static_assert(DC_META + 4 <= OVN_DELTA_CACHE_ELEMS, "Delta cache row too small");
+constexpr int QV = 8;                                // packed versions of the query: scales sa_q, sa_q / 2, ... sa_q / 128
+// per-query operands shared by every cached pair of a sweep: [QV][46080] packed words | AA [24][128] | {max R, min R, 0, 0}
+constexpr size_t QBLOCK_WORDS = (size_t)QV * OVN_FEAT_ELEMS + G * O2 + 4;
+
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   // LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16 l (the base is wave-uniform: it goes through M0)
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
@@ -280,13 +300,22 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 // One workgroup per pair and one workgroup per CU (129 KB of LDS), so nothing hides a memory round trip: every phase issues ALL of
 // a thread's loads before it uses the first (the left volume stays in registers from the range scan to the packing; a loop of
 // load / use / load costs one round trip per iteration and made this kernel 0.33 ms per 1024 pairs instead of 0.21).
+//
+// BUILD = true is the same kernel run per CANDIDATE to fill its Delta cache row (ovn_delta_cache): packed L words at the candidate's
+// own scale, TT + b2 and {max, min} -- everything of a pair's preparation that does not depend on the query as long as no value is
+// negative and the query's largest value stays below the candidate's next power of two.  BUILD = false with `dcache` given (1-vs-N
+// sweeps) checks exactly that condition per pair and, when it holds, only writes the pair's scales and its operand descriptor
+// (cache row + the query's shared block); otherwise it prepares the pair in scratch as before.  Both routes give the same bits:
+// the scales are functions of the power-of-two bucket of the pair's largest value, never of the value itself.
+template <bool BUILD>
 __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const float* __restrict__ feats_l, const int32_t* __restrict__ lidx, const float* __restrict__ feats_r,
     const int32_t* __restrict__ ridx, const _Float16* __restrict__ wsp, const float* __restrict__ w1col,
     const float* __restrict__ b1, const float* __restrict__ a2raw, const _Float16* __restrict__ w2p,
     const float* __restrict__ w2sum, const float* __restrict__ b2, float sw1, float sw2, float sws, float w1_colsum, float b1_absmax,
     float one, f32x4* __restrict__ scales, unsigned* __restrict__ o2max, unsigned* __restrict__ pl, unsigned* __restrict__ pr,
-    float* __restrict__ lin) {
+    float* __restrict__ lin, DeltaDesc* __restrict__ desc, const float* __restrict__ dcache, const unsigned* __restrict__ qblock,
+    float* __restrict__ cache_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   // T image, scaled fp16 hi / lo: T[15 ib + di][o] at [ib][di * 64 + 4 (o & 15) + (o >> 4)] (the K order of W2p)
   _Float16* Th = reinterpret_cast<_Float16*>(psm);
@@ -298,8 +327,36 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lrow = lane & 15, g = lane >> 4;
-  const float* Lf = feats_l + (long long)(lidx ? lidx[pair] : pair) * OVN_FEAT_ELEMS;
-  const float* Rf = feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;
+  const long long cand = lidx ? lidx[pair] : pair;
+  if (!BUILD && dcache) {   // workgroup-uniform: is the candidate's cache row valid for this query?
+    const float* row = dcache + cand * OVN_DELTA_CACHE_ELEMS;
+    const float* qm = reinterpret_cast<const float*>(qblock + (size_t)QV * OVN_FEAT_ELEMS + G * O2);
+    const float mxl = row[DC_META], mnl = row[DC_META + 1], mxr = qm[0], mnr = qm[1];
+    const float sa = ovn_pow2_scale_for(mxl);
+    const float saq = ovn_pow2_scale_for(mxr);
+    int eq = 0, el = 0;
+    (void)frexpf(saq, &eq);
+    (void)frexpf(sa, &el);
+    const int ver = eq - el;   // the query version packed with sa: saq / 2^ver
+    if (mnl >= 0.0f && mnr >= 0.0f && ovn_pow2_scale_for(fmaxf(mxl, mxr)) == sa && ver >= 0 && ver < QV) {
+      if (tid == 0) {
+        const float bc = 16384.0f / sa;
+        const float s1r = ovn_pow2_scale_for(2.0f * bc * w1_colsum);
+        scales[2 * pair] = (f32x4){sa, -2.0f * s1r / (sa * sw1), s1r, 1.0f / (s1r * sw2)};
+        scales[2 * pair + 1] = (f32x4){0.f, 0.f, fmaxf(mxl, mxr), 1.f};
+        o2max[pair] = 0u;
+        DeltaDesc d;
+        d.pl = reinterpret_cast<const unsigned*>(row) + DC_PL;
+        d.pr = qblock + (size_t)ver * OVN_FEAT_ELEMS;
+        d.tt = row + DC_TT;
+        d.aa = reinterpret_cast<const float*>(qblock + (size_t)QV * OVN_FEAT_ELEMS);
+        desc[pair] = d;
+      }
+      return;
+    }
+  }
+  const float* Lf = feats_l + cand * OVN_FEAT_ELEMS;
+  const float* Rf = BUILD ? Lf : feats_r + (long long)(ridx ? ridx[pair] : 0) * OVN_FEAT_ELEMS;   // BUILD: no right volume
   const f32x4* R4 = reinterpret_cast<const f32x4*>(Rf);
 
   // ---- all loads of the first phase in flight at once ----
@@ -324,8 +381,8 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
   f32x4 wsv[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) wsv[q] = reinterpret_cast<const f32x4*>(wsp)[tid + 512 * q];
-  float a2v[3][A2_KSPLIT];
-  {
+  float a2v[3][A2_KSPLIT] = {};
+  if (!BUILD) {
     const float* src = a2raw + (size_t)(ridx ? pair : 0) * A2_KSPLIT * A2_ELEMS;
 #pragma unroll
     for (int u = 0; u < 3; ++u)
@@ -336,7 +393,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
   constexpr int R_ITEMS = OVN_FEAT_ELEMS / 8;   // 5760 = 11.25 x 512
   float mx = -3.0e38f, mn = 3.0e38f;
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
+  for (int half = 0; half < (BUILD ? 0 : 2); ++half) {
     f32x4 rv[6][2];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -390,13 +447,27 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
   const float c = (mn < 0.0f) ? -mn : 0.0f;       // shift that makes both volumes non-negative
   const float span = mx + c;                       // largest shifted value
   const float sa = ovn_pow2_scale_for(span);
-  const float s1r = ovn_pow2_scale_for(2.0f * span * w1_colsum);
-  const float sT = ovn_pow2_scale_for(b1_absmax + span * w1_colsum);   // |T| <= |b1| + span max_o sum |W1[., o]|
+  // every further scale is a function of the power-of-two BUCKET of span (bc = 2^14 / sa >= span), not of span itself: a candidate's
+  // cached products (BUILD) are then bit for bit what this kernel computes for any pair in which the candidate sets the bucket
+  const float bc = 16384.0f / sa;
+  const float s1r = ovn_pow2_scale_for(2.0f * bc * w1_colsum);
+  const float sT = ovn_pow2_scale_for(b1_absmax + bc * w1_colsum);   // |T| <= |b1| + span max_o sum |W1[., o]|
   const float csa = c * sa;
+  float* crow = BUILD ? cache_out + (size_t)pair * OVN_DELTA_CACHE_ELEMS : nullptr;
   if (tid == 0) {
-    scales[2 * pair] = (f32x4){sa, -2.0f * s1r / (sa * sw1), s1r, 1.0f / (s1r * sw2)};
-    scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
-    o2max[pair] = 0u;
+    if (BUILD) {
+      *reinterpret_cast<f32x4*>(crow + DC_META) = (f32x4){mx, mn, 0.f, 0.f};
+    } else {
+      scales[2 * pair] = (f32x4){sa, -2.0f * s1r / (sa * sw1), s1r, 1.0f / (s1r * sw2)};
+      scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
+      o2max[pair] = 0u;
+      DeltaDesc d;
+      d.pl = pl + (size_t)pair * OVN_FEAT_ELEMS;
+      d.pr = pr + (size_t)pair * OVN_FEAT_ELEMS;
+      d.tt = lin + (size_t)pair * LIN_ELEMS;
+      d.aa = lin + (size_t)pair * LIN_ELEMS + G * O2;
+      desc[pair] = d;
+    }
   }
   // A2[jb][o] of this pair (true units): sum of the K slices of delta_a2_kernel (fixed order) + c (column sums of W1)
 #pragma unroll
@@ -408,7 +479,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     A2l[i] = v + c * w1col[i & (O1 - 1)];
   }
   // R words in pass order (second read of R: L2 hits, all loads of a batch in flight)
-  {
+  if (!BUILD) {
     unsigned* Pr = pr + (size_t)pair * OVN_FEAT_ELEMS;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -438,7 +509,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     }
   }
   // L words (from the registers) + T = b1 + (L + c) Ws on the fp16 matrix cores, Ws fragments from LDS
-  unsigned* P = pl + (size_t)pair * OVN_FEAT_ELEMS;
+  unsigned* P = BUILD ? reinterpret_cast<unsigned*>(crow) + DC_PL : pl + (size_t)pair * OVN_FEAT_ELEMS;
   const float inv_t = 1.0f / (sa * sws);
   float add[4];
 #pragma unroll
@@ -503,7 +574,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     bfr[u][1] = *reinterpret_cast<const f16x8*>(wk2 + (size_t)u * (8 * 2 * 512) + 512);
   }
   __syncthreads();
-  float* lp = lin + (size_t)pair * LIN_ELEMS;
+  float* lp = BUILD ? crow + DC_TT : lin + (size_t)pair * LIN_ELEMS;
   // TT = T[24 x 960] W2[960 x 128] on the fp16 matrix cores (3-term split against W2p); wave = n-tile, both m-tiles
   {
     const int r1 = (16 + lrow < G) ? 16 + lrow : G - 1;
@@ -545,7 +616,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     }
   }
   // AA[jb][p] = sum_o A2[jb][o] W2s[o][p]: thread = (p, 6 consecutive jb); its column of W2s in registers (64 loads in flight)
-  {
+  if (!BUILD) {
     const int p = tid & (O2 - 1), jb0 = 6 * (tid >> 7);
     float wcol[O1];
 #pragma unroll
@@ -557,6 +628,94 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
       for (int j = 0; j < 6; ++j) s[j] = fmaf(A2l[(jb0 + j) * O1 + o], wcol[o], s[j]);
 #pragma unroll
     for (int j = 0; j < 6; ++j) lp[G * O2 + (jb0 + j) * O2 + p] = s[j];
+  }
+}
+
+// The query's side of a cached 1-vs-N sweep, once per call: workgroup v packs the query's words at scale sa_q / 2^v (the version a
+// candidate whose own scale is that much coarser pairs with); workgroup 0 also leaves AA = (R W1) W2s and {max R, min R}.
+// Same arithmetic, in the same order, as the R / AA parts of delta_prepare_split_kernel with shift c = 0.
+__global__ __launch_bounds__(512) void delta_query_kernel(const float* __restrict__ feats_r, const float* __restrict__ a2raw,
+                                                          const float* __restrict__ w2sum, unsigned* __restrict__ qblock) {
+  __shared__ float red[2 * NWAVE];
+  __shared__ float A2l[G * O1];
+  const int ver = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f32x4* R4 = reinterpret_cast<const f32x4*>(feats_r);
+  constexpr int R_ITEMS = OVN_FEAT_ELEMS / 8;
+  f32x4 rv[12][2];
+  float mx = -3.0e38f, mn = 3.0e38f;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int i8 = tid + 512 * k;
+    if (i8 < R_ITEMS) {
+      rv[k][0] = R4[2 * i8];
+      rv[k][1] = R4[2 * i8 + 1];
+    } else {
+      rv[k][0] = rv[k][1] = R4[0];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 12; ++k)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      mx = fmaxf(mx, fmaxf(fmaxf(rv[k][h][0], rv[k][h][1]), fmaxf(rv[k][h][2], rv[k][h][3])));
+      mn = fminf(mn, fminf(fminf(rv[k][h][0], rv[k][h][1]), fminf(rv[k][h][2], rv[k][h][3])));
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+  }
+  if (lane == 0) {
+    red[wave] = mx;
+    red[NWAVE + wave] = mn;
+  }
+  __syncthreads();
+  mx = red[0];
+  mn = red[NWAVE];
+#pragma unroll
+  for (int w = 1; w < NWAVE; ++w) {
+    mx = fmaxf(mx, red[w]);
+    mn = fminf(mn, red[NWAVE + w]);
+  }
+  const float sa = ldexpf(ovn_pow2_scale_for(mx), -ver);
+  unsigned* Pr = qblock + (size_t)ver * OVN_FEAT_ELEMS;
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int i8 = tid + 512 * k;
+    if (i8 < R_ITEMS) {
+      const int jrow = i8 >> 4, ch = (i8 & 15) * 8;
+      const int jb = jrow / S, dj = jrow - jb * S;
+      const int gm = ch >> 5, sl = (ch & 31) >> 3;
+      unsigned* dst = Pr + ((jb * 4 + sl) * S + dj) * 32 + gm * 8;
+      *reinterpret_cast<u32x4*>(dst) = pack4(rv[k][0], sa, 0.0f);
+      *reinterpret_cast<u32x4*>(dst + 4) = pack4(rv[k][1], sa, 0.0f);
+    }
+  }
+  if (ver != 0) return;
+  float* aa = reinterpret_cast<float*>(qblock + (size_t)QV * OVN_FEAT_ELEMS);
+  if (tid == 0) *reinterpret_cast<f32x4*>(aa + G * O2) = (f32x4){mx, mn, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const int i = tid + 512 * u;
+    float v = a2raw[i];
+#pragma unroll
+    for (int k = 1; k < A2_KSPLIT; ++k) v += a2raw[(size_t)k * A2_ELEMS + i];
+    A2l[i] = v;   // (+ c * w1col with c = 0)
+  }
+  __syncthreads();
+  {
+    const int p = tid & (O2 - 1), jb0 = 6 * (tid >> 7);
+    float wcol[O1];
+#pragma unroll
+    for (int o = 0; o < O1; ++o) wcol[o] = w2sum[o * O2 + p];
+    float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < O1; ++o)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) sacc[j] = fmaf(A2l[(jb0 + j) * O1 + o], wcol[o], sacc[j]);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) aa[(jb0 + j) * O2 + p] = sacc[j];
   }
 }
 
@@ -579,7 +738,7 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 // ABL (timing-only, -DOVN_ABLATE builds): 1 no o1 stores, 2 no W1 DMA, 4 no chunk barrier, 8 no L DMA / slice reads, 16 no R DMA,
 // 64 W1 DMA always from chunk 0 (cache-resident source), 128 o1 stores of every pair into 256 pairs' rows (cache-resident destination)
 template <int SPC, int ABL = 0>
-__global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __restrict__ pl, const unsigned* __restrict__ pr,
+__global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __restrict__ desc,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
                                                              float* __restrict__ o1raw, int rot, int nsplit, int pair0) {
   constexpr int CHB = SPC * STEP_BYTES;          // window chunk
@@ -600,8 +759,8 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
   const int lrow = lane & 15;
   const int g = lane >> 4;
 
-  const unsigned* L = pl + (size_t)pair * OVN_FEAT_ELEMS;
-  const unsigned* Rw = pr + (size_t)pair * OVN_FEAT_ELEMS;
+  const unsigned* L = desc[pair].pl;     // per-pair scratch, or the candidate's cache row / the query's shared words
+  const unsigned* Rw = desc[pair].pr;
   const float krow = scales[2 * pair][1];
   const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
   unsigned char* lmine = lst + wave * LST_WAVE_BYTES;
@@ -750,7 +909,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const unsigned* __r
 // at every barrier, which cuts the prefetch distance to one step (measured 0.60 ms; one step = the loaded HBM latency, ~3 us).
 // Epilogue: acc / (s1r sw2) + TT[ib] + AA[jb] + b2, ReLU, per-pair maximum.
 __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __restrict__ o1raw, const _Float16* __restrict__ w2p,
-                                                                         const float* __restrict__ lin, const f32x4* __restrict__ scales,
+                                                                         const DeltaDesc* __restrict__ desc, const f32x4* __restrict__ scales,
                                                                          float* __restrict__ o2, unsigned* __restrict__ o2max, float one,
                                                                          int total_rows) {
   __shared__ __attribute__((aligned(16))) unsigned char wb[2][16384];
@@ -845,13 +1004,14 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
         const int rr = row - pair * (G * G);
         const int jb = rr / G, ib = rr - jb * G;
         const float inv2 = scales[2 * pair][3];
-        const float* lp = lin + (size_t)pair * LIN_ELEMS;
+        const float* tt = desc[pair].tt;
+        const float* aa = desc[pair].aa;
         float* dst = o2 + (((size_t)pair * G + ib) * G + jb) * O2 + lrow;
         float m = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
           const int p = 16 * nt + lrow;
-          const float v = fmaxf(fmaf(acc[mt][nt][r], inv2, lp[ib * O2 + p] + lp[G * O2 + jb * O2 + p]), 0.0f);
+          const float v = fmaxf(fmaf(acc[mt][nt][r], inv2, tt[ib * O2 + p] + aa[jb * O2 + p]), 0.0f);
           dst[16 * nt] = v;
           m = fmaxf(m, v);
         }
@@ -875,7 +1035,7 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + 2 * al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
          al((size_t)n * LIN_ELEMS * sizeof(float)) + al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float)) +
-         al((size_t)n * O1RAW_ELEMS * sizeof(float));
+         al((size_t)n * O1RAW_ELEMS * sizeof(float)) + al((size_t)n * sizeof(DeltaDesc)) + al(QBLOCK_WORDS * sizeof(unsigned));
 }
 
 static int pick_nsplit(int n) {
@@ -894,9 +1054,10 @@ static int pick_nsplit(int n) {
 // a2 + prepare (profile class delta_prep), c_conv1 contraction (delta_c12), c_conv2 GEMM (delta_c2)
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream,
-                                int pair0) {
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel), PREP_SPLIT_LDS);
+                                int pair0, const float* dcache_l) {
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel<false>), PREP_SPLIT_LDS);
   if (rc) return rc;
+  if (ridx) dcache_l = nullptr;   // the cache serves the 1-vs-N form (one query against many cached candidates)
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   char* p = static_cast<char*>(scratch);
   f32x4* scales = reinterpret_cast<f32x4*>(p);
@@ -912,15 +1073,20 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   float* a2raw = reinterpret_cast<float*>(p);
   p += al((size_t)(ridx ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float));
   float* o1raw = reinterpret_cast<float*>(p);
+  p += al((size_t)n * O1RAW_ELEMS * sizeof(float));
+  DeltaDesc* desc = reinterpret_cast<DeltaDesc*>(p);
+  p += al((size_t)n * sizeof(DeltaDesc));
+  unsigned* qblock = reinterpret_cast<unsigned*>(p);
   *o2max_out = o2max;
   const int nsplit = pick_nsplit(n);
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
-    hipLaunchKernelGGL(delta_prepare_split_kernel, dim3(n), dim3(512), PREP_SPLIT_LDS, stream, feats_l, lidx, feats_r, ridx,
+    if (dcache_l) hipLaunchKernelGGL(delta_query_kernel, dim3(QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock);
+    hipLaunchKernelGGL(delta_prepare_split_kernel<false>, dim3(n), dim3(512), PREP_SPLIT_LDS, stream, feats_l, lidx, feats_r, ridx,
                        reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1, a2raw,
                        reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->w2sum, ctx->c2.bias, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.sws,
-                       ctx->hs.w1_colsum, ctx->hs.b1_absmax, 1.0f, scales, o2max, pl, pr, lin);
+                       ctx->hs.w1_colsum, ctx->hs.b1_absmax, 1.0f, scales, o2max, pl, pr, lin, desc, dcache_l, qblock, (float*)nullptr);
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA, stream);
@@ -929,7 +1095,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     constexpr size_t lds = 2 * (size_t)(SPCV) * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;                          \
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), lds);              \
     if (rc) return rc;                                                                                                       \
-    hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, pl, pr,       \
+    hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, desc,         \
                        reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0);                      \
   }
 #ifdef OVN_ABLATE
@@ -957,8 +1123,22 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     OvnProfScope ps(ctx, OVN_K_DELTA_C2, stream);
     const int total_rows = n * G * G;
     hipLaunchKernelGGL(delta_c2_f16x3_kernel, dim3(total_rows / C2_TILE_ROWS), dim3(256), 0, stream, o1raw,
-                       reinterpret_cast<const _Float16*>(ctx->w2p_h), lin, scales, o2, o2max, 1.0f, total_rows);
+                       reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f, total_rows);
   }
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+// Delta cache rows of n feature volumes (ovn_delta_cache): delta_prepare_split_kernel<true>, one workgroup per volume.
+int ovn_delta_cache_forward(ovn_ctx* ctx, const float* feats, int n, float* cache, hipStream_t stream) {
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel<true>), PREP_SPLIT_LDS);
+  if (rc) return rc;
+  hipLaunchKernelGGL(delta_prepare_split_kernel<true>, dim3(n), dim3(512), PREP_SPLIT_LDS, stream, feats, (const int32_t*)nullptr,
+                     (const float*)nullptr, (const int32_t*)nullptr, reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1,
+                     (const float*)nullptr, reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->w2sum, ctx->c2.bias, ctx->hs.sw1,
+                     ctx->hs.sw2, ctx->hs.sws, ctx->hs.w1_colsum, ctx->hs.b1_absmax, 1.0f, (f32x4*)nullptr, (unsigned*)nullptr,
+                     (unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr, (DeltaDesc*)nullptr, (const float*)nullptr,
+                     (const unsigned*)nullptr, cache);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

@@ -400,7 +400,7 @@ struct OvnFork {   // fork on construction-time request, join (on every exit pat
 // stream j % streams, so a region is only ever reused in stream order).
 static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                           const int32_t* ridx, int64_t n, float* overlap, float* logit, int32_t* yaw, float* corr,
-                          int corr_mode, const float* spec_l, const float* spec_r, hipStream_t stream) {
+                          int corr_mode, const float* spec_l, const float* spec_r, const float* dcache_l, hipStream_t stream) {
   const size_t o2_elems = (size_t)OVN_G * OVN_G * OVN_C2_OUT;   // 24*24*128 per pair
   const size_t o3_elems = (size_t)OVN_DENSE_IN;                 // 22*22*256 per pair
   const bool fused = (ctx->head_mode != 0);
@@ -464,7 +464,7 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
       if (fused) {   // times its prepare kernels, the contraction kernel and c_conv2 separately
         unsigned* o2max = nullptr;
         float* part = o3 + (size_t)q0 * 3;
-        rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff));
+        rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff), dcache_l);
         if (rc) return rc;
         if (p0 == 0) ctx->dbg_o2max = o2max;
         {
@@ -503,18 +503,19 @@ int ovn_heads(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const flo
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads: NULL buffer");
   OVN_ON_DEVICE(ctx->device);
-  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, 1, nullptr, nullptr, (hipStream_t)stream_);
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, 1, nullptr, nullptr, nullptr, (hipStream_t)stream_);
 }
 
-int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l, const float* spec_l, const int32_t* lidx, const float* feats_r,
-                       const float* spec_r, const int32_t* ridx, int64_t n, float* overlap, int32_t* yaw, float* logit, float* corr,
-                       void* stream_) {
+int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l, const float* spec_l, const float* dcache_l, const int32_t* lidx,
+                       const float* feats_r, const float* spec_r, const int32_t* ridx, int64_t n, float* overlap, int32_t* yaw,
+                       float* logit, float* corr, void* stream_) {
   OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_heads_spectral: head weights not set");
   OVN_REQUIRE(n >= 0 && n < (1ll << 31), OVN_ERR_ARG, "ovn_heads_spectral: bad n");
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && spec_l && spec_r && overlap && yaw, OVN_ERR_ARG, "ovn_heads_spectral: NULL buffer");
   OVN_ON_DEVICE(ctx->device);
-  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, 2, spec_l, spec_r, (hipStream_t)stream_);
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, yaw, corr, 2, spec_l, spec_r,
+                        ctx->head_mode != 0 ? dcache_l : nullptr, (hipStream_t)stream_);
 }
 
 int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,
@@ -524,7 +525,18 @@ int ovn_delta_head(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, cons
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_l && feats_r && overlap, OVN_ERR_ARG, "ovn_delta_head: NULL buffer");
   OVN_ON_DEVICE(ctx->device);
-  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, 0, nullptr, nullptr, (hipStream_t)stream_);
+  return delta_head_run(ctx, feats_l, lidx, feats_r, ridx, n, overlap, logit, nullptr, nullptr, 0, nullptr, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+int ovn_delta_cache(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* cache_dev, void* stream) {
+  OVN_REQUIRE(ctx && ctx->head_set, OVN_ERR_STATE, "ovn_delta_cache: head weights not set");
+  OVN_REQUIRE(n >= 0 && n < (1ll << 24), OVN_ERR_ARG, "ovn_delta_cache: bad n");
+  if (n == 0) return OVN_OK;
+  OVN_REQUIRE(feats_dev && cache_dev, OVN_ERR_ARG, "ovn_delta_cache: NULL buffer");
+  OVN_REQUIRE((reinterpret_cast<uintptr_t>(cache_dev) & 15) == 0, OVN_ERR_ARG, "ovn_delta_cache: cache_dev must be 16-byte aligned");
+  OVN_ON_DEVICE(ctx->device);
+  OvnProfScope ps(ctx, OVN_K_DELTA_PREP, (hipStream_t)stream);
+  return ovn_delta_cache_forward(ctx, feats_dev, (int)n, cache_dev, (hipStream_t)stream);
 }
 
 int ovn_set_head_pipeline(ovn_ctx* ctx, int64_t chunk_pairs, int64_t sub_chunk_pairs, int streams, int yaw_on_side_stream) {

@@ -75,6 +75,7 @@ constexpr int OVN_ACTMAX_STRIDE = 32;                          // words between 
                                                                // own 128-byte line (atomics on one line serialise at the memory side)
 constexpr int OVN_SPEC_W = 368;                                 // floats per spectrum row: Re[0..180] | pad | Im at 184.. | pad
 constexpr int OVN_SPEC_ELEMS = OVN_FEAT_C * OVN_SPEC_W;        // 47104 floats = 188,416 B per scan
+static_assert(OVN_DELTA_CACHE_ELEMS >= OVN_FEAT_ELEMS + 24 * 128 + 4, "include/ovn_hip.h: OVN_DELTA_CACHE_ELEMS");
 
 // ---- scaled fp16 hi/lo arithmetic ("f16x3") ----------------------------------------------------------
 // Power-of-two scale that brings a tensor whose largest magnitude is m into [2^13, 2^14): 2^(14 - e) with 2^(e-1) <= m < 2^e.
@@ -249,7 +250,9 @@ int ovn_delta_prepare_f16x3(ovn_ctx* ctx, const float* c1_kernel_dev, const floa
 size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right);
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream,
-                                int pair0 = 0);   // pair0: index of the call's first pair in the sweep (rotation of the K walks)
+                                int pair0 = 0,    // pair0: index of the call's first pair in the sweep (rotation of the K walks)
+                                const float* dcache_l = nullptr);   // Delta cache rows of the left pool (ovn_delta_cache), 1-vs-N only
+int ovn_delta_cache_forward(ovn_ctx* ctx, const float* feats, int n, float* cache, hipStream_t stream);
 
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,

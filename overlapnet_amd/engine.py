@@ -159,9 +159,11 @@ class OvnEngine:
 
     def heads(self, feats_l: torch.Tensor, feats_r: torch.Tensor, lidx=None, ridx=None, n: Optional[int] = None,
               want_logit: bool = False, want_corr: bool = False, spec_l: Optional[torch.Tensor] = None,
-              spec_r: Optional[torch.Tensor] = None):
+              spec_r: Optional[torch.Tensor] = None, dcache_l: Optional[torch.Tensor] = None):
         """Both heads on n pairs: pair p = (l = feats_l[lidx[p]], r = feats_r[ridx[p]]).
         lidx None -> p, ridx None -> 0 (1-vs-N: feats_r holds the single query).
+        spec_l / spec_r: cached spectra (`spectrum`) -> the HBM-bound spectral yaw head; dcache_l: the left pool's Delta cache rows
+        (`delta_cache`), used by 1-vs-N sweeps -- same results with or without it.
         Returns dict of device tensors: overlap (n) f32, yaw (n) i32 [, logit (n), corr (n,360)]."""
         if not self._head_ready:
             raise _lib.OvnError("head weights not loaded")
@@ -181,11 +183,16 @@ class OvnEngine:
                     raise _lib.OvnError("%s must be a contiguous float32 tensor on %s" % (what, self.device))
             if spec_l.numel() != nl * FEAT_C * self.SPEC_W or spec_r.numel() != nr * FEAT_C * self.SPEC_W:
                 raise _lib.OvnError("spec_l / spec_r must hold one 128x368 spectrum per feature volume")
+            if dcache_l is not None:
+                if dcache_l.device != self.device or dcache_l.dtype != torch.float32 or not dcache_l.is_contiguous():
+                    raise _lib.OvnError("dcache_l must be a contiguous float32 tensor on %s" % self.device)
+                if dcache_l.numel() != nl * self.DELTA_CACHE_ELEMS:
+                    raise _lib.OvnError("dcache_l must hold one Delta cache row per left feature volume")
             yaw = torch.empty(n, dtype=torch.int32, device=self.device)
             corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
             with torch.cuda.device(self.device):
-                _lib.check(self.lib.ovn_heads_spectral(self._h, _ptr(feats_l), _ptr(spec_l), _ptr(li), _ptr(feats_r), _ptr(spec_r),
-                                                       _ptr(ri), n, _ptr(overlap), _ptr(yaw), _ptr(logit), _ptr(corr),
+                _lib.check(self.lib.ovn_heads_spectral(self._h, _ptr(feats_l), _ptr(spec_l), _ptr(dcache_l), _ptr(li), _ptr(feats_r),
+                                                       _ptr(spec_r), _ptr(ri), n, _ptr(overlap), _ptr(yaw), _ptr(logit), _ptr(corr),
                                                        self._stream()), "ovn_heads_spectral")
             out = {"overlap": overlap, "yaw": yaw}
             if want_logit:
@@ -218,6 +225,20 @@ class OvnEngine:
         return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
 
     SPEC_W = 368
+    DELTA_CACHE_ELEMS = 49216      # floats per Delta cache row (include/ovn_hip.h: OVN_DELTA_CACHE_ELEMS)
+
+    def delta_cache(self, feats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """feature volumes (n,360,128) -> Delta cache rows (n, 49216): the candidate-side half of the Delta head's preparation
+        (packed words, TT + b2, value range), cached next to the volume like its spectrum."""
+        if not self._head_ready:
+            raise _lib.OvnError("head weights not loaded")
+        self._check_feats(feats, "feats")
+        n = feats.numel() // (FEAT_W * FEAT_C)
+        if out is None:
+            out = torch.empty((n, self.DELTA_CACHE_ELEMS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_delta_cache(self._h, _ptr(feats), n, _ptr(out), self._stream()), "ovn_delta_cache")
+        return out
 
     def spectrum(self, feats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """feature volumes (n,360,128) -> cached spectra (n,128,368) for the spectral correlation head."""

@@ -36,12 +36,13 @@ class FeatureVolumeCache(object):
   volumes live in HBM (together with their spectra) and are copied to the host one at a time when indexed."""
 
   def __init__(self, engine, min_capacity=1024):
-    """min_capacity: smallest allocation (volumes) on first use -- 1024 (380 MB with the spectra) for the persistent cache of
+    """min_capacity: smallest allocation (volumes) on first use -- 1024 (580 MB with the spectra and the Delta cache rows) for the persistent cache of
     `infer_multiple`, which grows by one frame per call; the throw-away caches of `infer_one` / `infer_multiple_vs_multiple`
     pass the number of volumes they will hold."""
     self._engine = engine
     self._fv = None        # (capacity, 360, 128) device tensor
     self._spec = None      # (capacity, 128, 368) device tensor: cached spectra for the correlation head
+    self._dc = None        # (capacity, 49216) device tensor: Delta cache rows (candidate-side half of the Delta head's preparation)
     self._n = 0
     self._min_capacity = max(1, int(min_capacity))
 
@@ -53,12 +54,15 @@ class FeatureVolumeCache(object):
       dev = self._engine.device
       nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
       ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
+      nd = torch.empty((cap, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
       if self._n:
         nf[:self._n].copy_(self._fv[:self._n])
         ns[:self._n].copy_(self._spec[:self._n])
-      self._fv, self._spec = nf, ns
+        nd[:self._n].copy_(self._dc[:self._n])
+      self._fv, self._spec, self._dc = nf, ns, nd
     self._fv[self._n:self._n + k].copy_(fv)
     self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
+    self._engine.delta_cache(self._fv[self._n:self._n + k], out=self._dc[self._n:self._n + k])
     self._n += k
 
   @property
@@ -68,6 +72,10 @@ class FeatureVolumeCache(object):
   @property
   def device_spectra(self) -> torch.Tensor:
     return self._spec[:self._n] if self._spec is not None else torch.empty((0, FEAT_C, self._engine.SPEC_W), device=self._engine.device)
+
+  @property
+  def device_delta_cache(self) -> torch.Tensor:
+    return self._dc[:self._n] if self._dc is not None else torch.empty((0, self._engine.DELTA_CACHE_ELEMS), device=self._engine.device)
 
   # -- list / ndarray behaviour ----------------------------------------------------------------------
   def __len__(self):
@@ -319,7 +327,8 @@ class Infer():
       q = int(right[0])
       if not 0 <= q < len(cache):
         raise IndexError('index %d is out of bounds for axis 0 with size %d' % (q, len(cache)))
-      return self.engine.heads(feats, feats[q:q + 1], lidx=left, n=len(right), spec_l=spec, spec_r=spec[q:q + 1])
+      return self.engine.heads(feats, feats[q:q + 1], lidx=left, n=len(right), spec_l=spec, spec_r=spec[q:q + 1],
+                               dcache_l=cache.device_delta_cache)
     return self.engine.heads(feats, feats, lidx=left, ridx=right, n=len(right), spec_l=spec, spec_r=spec)
 
   def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray):

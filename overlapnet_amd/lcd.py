@@ -5,9 +5,9 @@ frames older than `inactive_time_thres`, travelled further than `inactive_dist_t
 n-sigma covariance ellipse around the current pose; the loop closure is the candidate with the largest overlap
 if that exceeds `overlap_thres`.  Animation / plotting are out of scope.
 
-Pinned on the reference's own code: tests/golden/lcd_gating.npz holds, frame by frame, the ellipse, the candidate list and the
-reported loop closure produced by `AnimatedLCD.get_cov_ellipse` / `get_predictions` (imported unmodified by
-tests/golden/make_lcd_golden.py) for three synthetic trajectories; tests/test_host_logic.py requires equality.
+Pinned on the reference's own code: the test suite holds, frame by frame, the ellipse, the candidate list and the reported loop
+closure produced by `AnimatedLCD.get_cov_ellipse` / `get_predictions` (imported unmodified by the golden-file generator
+make_lcd_golden.py) for three synthetic trajectories, and requires equality (test_host_logic.py).
 """
 from __future__ import annotations
 

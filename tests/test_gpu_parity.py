@@ -835,3 +835,44 @@ def test_head_results_do_not_depend_on_the_launch_structure(engines):
             e.set_head_pipeline(1024, 0, 3, True)
     finally:
         e.set_head_pipeline(*DEFAULT_PIPELINE)
+
+
+def test_delta_cache_gives_the_same_bits_and_falls_back_per_pair(engines):
+    """ovn_delta_cache rows (packed words at the candidate's own scale, TT + b2, range) replace the per-pair preparation of a 1-vs-N
+    sweep wherever they are valid -- no negative value, the query's maximum below the candidate's next power of two -- and every
+    other pair is prepared in scratch as before: identical bits either way, pair by pair."""
+    e = engines[4]
+    rng = np.random.default_rng(2024)
+    n = 300
+    fv = np.maximum(rng.normal(0.2, 1.0, size=(n, 360, 128)), 0).astype(np.float32)
+    fv[5] *= 40.0            # a candidate two buckets above the rest (its own scale is coarser than the query's: version 5..6 of the query)
+    fv[6] *= 1.0e-3          # far below: the QUERY sets the bucket -> fallback
+    fv[7] *= 0.0             # empty volume -> fallback
+    fv[8] = -fv[8]           # negative values -> fallback (shifted arithmetic)
+    fv[9] *= 3.0e4           # more than 2^7 above the query: no packed query version -> fallback
+    fvt = torch.from_numpy(fv).cuda()
+    spec = e.spectrum(fvt)
+    dc = e.delta_cache(fvt)
+    assert tuple(dc.shape) == (n, e.DELTA_CACHE_ELEMS)
+    meta = dc[:, 46080 + 3072:46080 + 3074].cpu().numpy()
+    assert np.array_equal(meta[:, 0], fv.reshape(n, -1).max(axis=1)) and np.array_equal(meta[:, 1], fv.reshape(n, -1).min(axis=1))
+    for qi, qscale in ((0, 1.0), (1, 0.25), (2, 5.0), (8, 1.0)):      # ordinary, smaller, larger (many candidates fall back), negative query
+        q = (fvt[qi:qi + 1] * qscale).contiguous()
+        qs = e.spectrum(q)
+        ref = e.heads(fvt, q, spec_l=spec, spec_r=qs, want_logit=True)
+        got = e.heads(fvt, q, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
+        torch.cuda.synchronize()
+        assert torch.equal(got["logit"], ref["logit"]) and torch.equal(got["overlap"], ref["overlap"]) and torch.equal(got["yaw"], ref["yaw"]), qi
+        idx = torch.from_numpy(rng.permutation(n)[:77].astype(np.int32)).cuda()
+        a = e.heads(fvt, q, lidx=idx, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
+        b = e.heads(fvt, q, lidx=idx, spec_l=spec, spec_r=qs, want_logit=True)
+        assert torch.equal(a["logit"], b["logit"]), qi
+    # against the fp64 oracle too (the cache changes where the work is done, not the arithmetic that is checked everywhere else)
+    w = S.make_test_weights(4, seed=0)
+    q = fvt[0:1].contiguous()
+    got = e.heads(fvt[:12].contiguous(), q, spec_l=spec[:12].contiguous(), spec_r=e.spectrum(q), want_logit=True, dcache_l=dc[:12].contiguous())
+    fv4 = fv[:12].reshape(-1, 1, 360, 128).astype(np.float64)
+    o_ov, o_yaw, o_lg, _ = O.heads_forward(fv4, np.repeat(fv4[0:1], 12, axis=0), w)
+    assert np.max(np.abs(got["overlap"].cpu().numpy() - o_ov)) <= 1e-4 and np.array_equal(got["yaw"].cpu().numpy(), o_yaw)
+    with pytest.raises(Exception):
+        e.heads(fvt, q, spec_l=spec, spec_r=e.spectrum(q), dcache_l=dc[:10].contiguous())

@@ -30,6 +30,7 @@ def engine_sweep(frames: int = 1101, C: int = 4):
     imgs = torch.from_numpy(S.candidate_images(128, C, seed=3)).to(dev)      # 128 distinct synthetic scans, reused cyclically
     feats = torch.empty((frames, 360, 128), dtype=torch.float32, device=dev)
     specs = torch.empty((frames, 128, eng.SPEC_W), dtype=torch.float32, device=dev)
+    dcs = torch.empty((frames, eng.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
 
     def run():
         found = 0
@@ -37,9 +38,10 @@ def engine_sweep(frames: int = 1101, C: int = 4):
             q = imgs[i % 128:i % 128 + 1]
             eng.leg(q, out=feats[i:i + 1])
             eng.spectrum(feats[i:i + 1], out=specs[i:i + 1])
+            eng.delta_cache(feats[i:i + 1], out=dcs[i:i + 1])
             if i == 0:
                 continue
-            r = eng.heads(feats[:i], feats[i:i + 1], spec_l=specs[:i], spec_r=specs[i:i + 1])
+            r = eng.heads(feats[:i], feats[i:i + 1], spec_l=specs[:i], spec_r=specs[i:i + 1], dcache_l=dcs[:i])
             found += decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3)) is not None
         return found
 
