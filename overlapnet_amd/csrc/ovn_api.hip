@@ -340,7 +340,7 @@ int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l, const int32_t* lid
 // A head call may spread its launches over the caller's stream and two context-owned side streams: the HBM-bound yaw head next to
 // the matrix-core-bound Delta kernels, and the sub-chunks of a sweep alternating between two streams so that the prepare / c_conv2 /
 // c_conv3 kernels of one sub-chunk run beside the contraction kernel of the next.  Fork and join are events on the caller's stream:
-// to the caller the call still behaves as if everything had been enqueued on `stream` (and it can be captured in a HIP graph).
+// to the caller the call still behaves as if everything had been enqueued on `stream`.
 static int head_streams_ready(ovn_ctx* ctx) {
   if (ctx->aux_ready) return OVN_OK;
   for (int i = 0; i < 2; ++i) {

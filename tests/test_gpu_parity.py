@@ -876,3 +876,25 @@ def test_delta_cache_gives_the_same_bits_and_falls_back_per_pair(engines):
     assert np.max(np.abs(got["overlap"].cpu().numpy() - o_ov)) <= 1e-4 and np.array_equal(got["yaw"].cpu().numpy(), o_yaw)
     with pytest.raises(Exception):
         e.heads(fvt, q, spec_l=spec, spec_r=e.spectrum(q), dcache_l=dc[:10].contiguous())
+
+
+def test_delta_cache_is_ignored_where_it_does_not_apply(engines):
+    """fp32 head mode and pair lists with their own right-hand volumes never use the Delta cache rows: same results as without."""
+    e = engines[4]
+    rng = np.random.default_rng(77)
+    fv = torch.from_numpy(np.maximum(rng.normal(0.2, 1.0, size=(20, 360, 128)), 0).astype(np.float32)).cuda()
+    spec, dc = e.spectrum(fv), e.delta_cache(fv)
+    li, ri = np.arange(20), (np.arange(20) * 7) % 20
+    a = e.heads(fv, fv, lidx=li, ridx=ri, spec_l=spec, spec_r=spec, want_logit=True, dcache_l=dc)
+    b = e.heads(fv, fv, lidx=li, ridx=ri, spec_l=spec, spec_r=spec, want_logit=True)
+    assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["yaw"], b["yaw"])
+    q = fv[3:4].contiguous()
+    e.set_head_precision("f32")
+    try:
+        qs = e.spectrum(q)
+        s32 = e.spectrum(fv)
+        a = e.heads(fv, q, spec_l=s32, spec_r=qs, want_logit=True, dcache_l=dc)
+        b = e.heads(fv, q, spec_l=s32, spec_r=qs, want_logit=True)
+        assert torch.equal(a["logit"], b["logit"])
+    finally:
+        e.set_head_precision(DEFAULT_HEAD)
