@@ -990,43 +990,45 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
 #undef OVN_LOAD_W
 #undef OVN_STORE_W
 
-  // rows of one m-tile (16 consecutive) lie in at most two pairs; a lane's 4 rows 4g .. 4g+3 may straddle the boundary too
+  // a workgroup's 192 rows belong to ONE pair (576 = 3 x 192): its scale and the pointers to its linear terms are wave-uniform
+  // (scalar loads, issued here and long landed when the epilogue needs them)
+  static_assert((G * G) % C2_TILE_ROWS == 0, "a c_conv2 workgroup must not straddle two pairs");
+  const int pair = blockIdx.x / (G * G / C2_TILE_ROWS);
+  const float inv2 = scales[2 * pair][3];
+  // (pointers loaded from memory are generic to the compiler: as flat loads they would force vmcnt(0) lgkmcnt(0) waits into the
+  // K loop's prefetch chain -- 0.60 -> 0.67 ms; say that they are global)
+  typedef const __attribute__((address_space(1))) float* gfloat_p;
+  const gfloat_p tt = (gfloat_p)desc[pair].tt;
+  const gfloat_p aa = (gfloat_p)desc[pair].aa;
+  // The linear terms of output row (mt, r) are loaded one row AHEAD of the row being stored: tt / aa are not `restrict` to the
+  // compiler (they come out of a descriptor), so it keeps every load behind the o2 stores that precede it in program order -- written
+  // naively that is one exposed L2 round trip per element (96 per lane: 0.60 -> 0.66 ms for the kernel)
+  float vmax = 0.f;
+  float lv[2][8];
+  auto load_lin = [&](int q, float* dst8) {   // q = 4 mt + r
+    const int rr = row0 + 16 * (q >> 2) - pair * (G * G) + 4 * g + (q & 3);
+    const int jb = rr / G, ib = rr - jb * G;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    float vmax[2] = {0.f, 0.f};
-    const int rbase = row0 + 16 * mt;
-    const int pair_lo = rbase / (G * G);
+    for (int nt = 0; nt < 8; ++nt) dst8[nt] = tt[ib * O2 + 16 * nt + lrow] + aa[jb * O2 + 16 * nt + lrow];
+  };
+  load_lin(0, lv[0]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rbase + 4 * g + r;
-      if (row < total_rows) {
-        const int pair = row / (G * G);
-        const int rr = row - pair * (G * G);
-        const int jb = rr / G, ib = rr - jb * G;
-        const float inv2 = scales[2 * pair][3];
-        const float* tt = desc[pair].tt;
-        const float* aa = desc[pair].aa;
-        float* dst = o2 + (((size_t)pair * G + ib) * G + jb) * O2 + lrow;
-        float m = 0.f;
+  for (int q = 0; q < 4 * MT; ++q) {
+    if (q + 1 < 4 * MT) load_lin(q + 1, lv[(q + 1) & 1]);
+    const int mt = q >> 2, r = q & 3;
+    const int rr = row0 + 16 * mt - pair * (G * G) + 4 * g + r;
+    const int jb = rr / G, ib = rr - jb * G;
+    float* dst = o2 + (((size_t)pair * G + ib) * G + jb) * O2 + lrow;
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-          const int p = 16 * nt + lrow;
-          const float v = fmaxf(fmaf(acc[mt][nt][r], inv2, tt[ib * O2 + p] + aa[jb * O2 + p]), 0.0f);
-          dst[16 * nt] = v;
-          m = fmaxf(m, v);
-        }
-        if (pair == pair_lo) vmax[0] = fmaxf(vmax[0], m);
-        else vmax[1] = fmaxf(vmax[1], m);
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      float v = vmax[h];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
-      if (lane == 0 && v > 0.f) atomicMax(o2max + pair_lo + h, __float_as_uint(v));
+    for (int nt = 0; nt < 8; ++nt) {
+      const float v = fmaxf(fmaf(acc[mt][nt][r], inv2, lv[q & 1][nt]), 0.0f);
+      dst[16 * nt] = v;
+      vmax = fmaxf(vmax, v);
     }
   }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) vmax = fmaxf(vmax, __shfl_down(vmax, off, 64));
+  if (lane == 0 && vmax > 0.f) atomicMax(o2max + pair, __float_as_uint(vmax));
 }
 
 }  // namespace
