@@ -67,6 +67,14 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1_kernel_dev, const float* 
                          const float* c3_kernel_dev, const float* c3_bias_dev,
                          const float* dense_kernel_dev, const float* dense_bias_dev, void* stream);
 
+/* Head geometry: `conv1NetworkHead_conv1size` of the reference's network.yml (generateNet.py:88-99: the 1 x s / s x 1 kernels and
+ * strides of c_conv1 / c_conv2; default 15, which the shipped configuration uses).  Call BEFORE ovn_set_head_weights when the
+ * model was built with another value: c_conv1 is then (1, s, 128, 64), c_conv2 (s, 1, 64, 128) and the Dense kernel has
+ * (360 // s - 2)^2 * 256 inputs.  The MFMA-tiled Delta kernels (both arithmetic modes) serve s = 15; any other s runs a general fp32
+ * path (DeltaLayer + c_conv1 as plain FMAs without materialising the difference tensor, c_conv2 / c_conv3 through the generic fp32
+ * convolution) -- correct to the same tolerance, an order of magnitude slower, no Delta cache. */
+int ovn_set_head_geometry(ovn_ctx* ctx, int conv1size);
+
 /* Validate the registered leg chain: output must be 1 x feat_w x 128 (1 x 360 x 128 in the reference).
  * Writes the leg output width to *feat_w. */
 int ovn_finalize(ovn_ctx* ctx, int* feat_w);

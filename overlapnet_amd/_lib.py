@@ -27,6 +27,7 @@ SIGNATURES = {
     "ovn_destroy": (C.c_int, [_vp]),
     "ovn_add_leg_layer": (C.c_int, [_vp, C.c_char_p, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "ovn_set_head_weights": (C.c_int, [_vp] + [_vp] * 8 + [_vp]),
+    "ovn_set_head_geometry": (C.c_int, [_vp, C.c_int]),
     "ovn_finalize": (C.c_int, [_vp, C.POINTER(C.c_int)]),
     "ovn_leg": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp]),
     "ovn_heads": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _vp]),

@@ -176,24 +176,35 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
     ctx->w1p = ctx->b1 = ctx->wd = ctx->bd = nullptr;
     ctx->head_set = false;
   }
-  int rc = ovn_delta_prepare_w1(c1k, &ctx->w1p, stream);
-  if (rc) return rc;
+  const int hs = ctx->head_s, hg = ctx->head_g;
+  const bool general = (hs != OVN_S);   // any other conv1size: general fp32 path (delta_head_generic.hip), no fast-path operands
+  int rc = OVN_OK;
+  if (!general) {
+    rc = ovn_delta_prepare_w1(c1k, &ctx->w1p, stream);
+    if (rc) return rc;
+  } else {
+    const size_t w1_bytes = (size_t)hs * OVN_FEAT_C * OVN_C1_OUT * sizeof(float);
+    OVN_HIP_CHECK(hipMalloc((void**)&ctx->w1raw, w1_bytes));
+    OVN_HIP_CHECK(hipMemcpyAsync(ctx->w1raw, c1k, w1_bytes, hipMemcpyDeviceToDevice, stream));
+  }
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->b1, OVN_C1_OUT * sizeof(float)));
   OVN_HIP_CHECK(hipMemcpyAsync(ctx->b1, c1b, OVN_C1_OUT * sizeof(float), hipMemcpyDeviceToDevice, stream));
   // c_conv2 (15,1,64,128): as a GEMM operand it is the [960][128] matrix, k = di*64 + o
   ctx->c2 = OvnConvLayer();
   ctx->c2.name = "c_conv2";
-  ctx->c2.kh = OVN_S;
+  ctx->c2.kh = hs;
   ctx->c2.kw = 1;
   ctx->c2.cin = OVN_C1_OUT;
   ctx->c2.cout = OVN_C2_OUT;
-  ctx->c2.sh = OVN_S;
+  ctx->c2.sh = hs;
   ctx->c2.sw = 1;
   ctx->c2.relu = 1;
   rc = ovn_conv_prepare(&ctx->c2, c2k, c2b, stream);
   if (rc) return rc;
-  rc = ovn_delta_prepare_f16x3(ctx, c1k, c1b, c2k, stream);
-  if (rc) return rc;
+  if (!general) {
+    rc = ovn_delta_prepare_f16x3(ctx, c1k, c1b, c2k, stream);
+    if (rc) return rc;
+  }
   ctx->c3 = OvnConvLayer();
   ctx->c3.name = "c_conv3";
   ctx->c3.kh = 3;
@@ -205,11 +216,14 @@ int ovn_set_head_weights(ovn_ctx* ctx, const float* c1k, const float* c1b, const
   ctx->c3.relu = 1;
   rc = ovn_conv_prepare(&ctx->c3, c3k, c3b, stream);
   if (rc) return rc;
-  rc = ovn_conv_prepare_f16x3(&ctx->c3, c3k, stream);
-  if (rc) return rc;
-  OVN_HIP_CHECK(hipMalloc((void**)&ctx->wd, (size_t)OVN_DENSE_IN * sizeof(float)));
+  if (!general) {
+    rc = ovn_conv_prepare_f16x3(&ctx->c3, c3k, stream);
+    if (rc) return rc;
+  }
+  const size_t dense_in = (size_t)(hg - 2) * (hg - 2) * OVN_C3_OUT;   // 123904 at conv1size 15
+  OVN_HIP_CHECK(hipMalloc((void**)&ctx->wd, dense_in * sizeof(float)));
   OVN_HIP_CHECK(hipMalloc((void**)&ctx->bd, sizeof(float)));
-  OVN_HIP_CHECK(hipMemcpyAsync(ctx->wd, dk, (size_t)OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice, stream));
+  OVN_HIP_CHECK(hipMemcpyAsync(ctx->wd, dk, dense_in * sizeof(float), hipMemcpyDeviceToDevice, stream));
   OVN_HIP_CHECK(hipMemcpyAsync(ctx->bd, db, sizeof(float), hipMemcpyDeviceToDevice, stream));
   OVN_HIP_CHECK(hipStreamSynchronize(stream));
   ctx->head_set = true;
@@ -401,6 +415,38 @@ struct OvnFork {   // fork on construction-time request, join (on every exit pat
 static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                           const int32_t* ridx, int64_t n, float* overlap, float* logit, int32_t* yaw, float* corr,
                           int corr_mode, const float* spec_l, const float* spec_r, const float* dcache_l, hipStream_t stream) {
+  if (ctx->head_s != OVN_S) {   // general conv1size: fp32 generality path, chunked so that the scratch stays near 2 GB
+    const size_t pb = ovn_delta_generic_pair_bytes(ctx->head_g);
+    int64_t chunk = (int64_t)((2ull << 30) / pb);
+    chunk = chunk < 1 ? 1 : (chunk > 1024 ? 1024 : chunk);
+    const int64_t cmax = n < chunk ? n : chunk;
+    int rc = ovn_ws_reserve(ctx, (size_t)cmax * pb + 1024, stream);
+    if (rc) return rc;
+    ctx->dbg_o2 = ctx->dbg_o3 = nullptr;
+    ctx->dbg_partial = nullptr;
+    ctx->dbg_o2max = nullptr;
+    ctx->dbg_n = 0;
+    if (corr_mode == 2) {
+      OvnProfScope ps(ctx, OVN_K_CORR_SPECTRAL, stream);
+      rc = ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, stream);
+      if (rc) return rc;
+    }
+    for (int64_t p0 = 0; p0 < n; p0 += chunk) {
+      const int np = (int)((n - p0 < chunk) ? (n - p0) : chunk);
+      const float* fl = lidx ? feats_l : feats_l + (size_t)p0 * OVN_FEAT_ELEMS;
+      const int32_t* li = lidx ? lidx + p0 : nullptr;
+      const int32_t* ri = ridx ? ridx + p0 : nullptr;
+      if (corr_mode == 1) {
+        OvnProfScope ps(ctx, OVN_K_CORR, stream);
+        rc = ovn_corr_forward(fl, li, feats_r, ri, np, yaw + p0, corr ? corr + (size_t)p0 * OVN_FEAT_W : nullptr, stream);
+        if (rc) return rc;
+      }
+      OvnProfScope ps(ctx, OVN_K_DELTA, stream);
+      rc = ovn_delta_generic_forward(ctx, fl, li, feats_r, ri, np, ctx->ws, overlap + p0, logit ? logit + p0 : nullptr, stream);
+      if (rc) return rc;
+    }
+    return OVN_OK;
+  }
   const size_t o2_elems = (size_t)OVN_G * OVN_G * OVN_C2_OUT;   // 24*24*128 per pair
   const size_t o3_elems = (size_t)OVN_DENSE_IN;                 // 22*22*256 per pair
   const bool fused = (ctx->head_mode != 0);
@@ -534,9 +580,20 @@ int ovn_delta_cache(ovn_ctx* ctx, const float* feats_dev, int64_t n, float* cach
   if (n == 0) return OVN_OK;
   OVN_REQUIRE(feats_dev && cache_dev, OVN_ERR_ARG, "ovn_delta_cache: NULL buffer");
   OVN_REQUIRE((reinterpret_cast<uintptr_t>(cache_dev) & 15) == 0, OVN_ERR_ARG, "ovn_delta_cache: cache_dev must be 16-byte aligned");
+  OVN_REQUIRE(ctx->head_s == OVN_S, OVN_ERR_STATE, "ovn_delta_cache: only the default head geometry (conv1size 15) has a Delta cache");
   OVN_ON_DEVICE(ctx->device);
   OvnProfScope ps(ctx, OVN_K_DELTA_PREP, (hipStream_t)stream);
   return ovn_delta_cache_forward(ctx, feats_dev, (int)n, cache_dev, (hipStream_t)stream);
+}
+
+int ovn_set_head_geometry(ovn_ctx* ctx, int conv1size) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_geometry: ctx is NULL");
+  OVN_REQUIRE(!ctx->head_set, OVN_ERR_STATE, "ovn_set_head_geometry: call it before ovn_set_head_weights");
+  OVN_REQUIRE(conv1size >= 1 && OVN_FEAT_W / conv1size >= 3, OVN_ERR_ARG,
+              "ovn_set_head_geometry: conv1size %d leaves fewer than 3 x 3 groups of the 360 columns for c_conv3", conv1size);
+  ctx->head_s = conv1size;
+  ctx->head_g = OVN_FEAT_W / conv1size;
+  return OVN_OK;
 }
 
 int ovn_set_head_pipeline(ovn_ctx* ctx, int64_t chunk_pairs, int64_t sub_chunk_pairs, int streams, int yaw_on_side_stream) {

@@ -146,6 +146,8 @@ struct ovn_ctx {
   int feat_w = 0;
   // head
   bool head_set = false;
+  int head_s = OVN_S;      // conv1NetworkHead_conv1size (ovn_set_head_geometry); the fast Delta paths serve 15, anything else the
+  int head_g = OVN_G;      // general fp32 path of delta_head_generic.hip; head_g = 360 // head_s
   float* w1p = nullptr;  // c_conv1 in the K-permuted fragment order of the fused kernel
   float* b1 = nullptr;
   OvnConvLayer c2;       // c_conv2 as a [960][128] GEMM operand in fragment order
@@ -253,6 +255,11 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
                                 int pair0 = 0,    // pair0: index of the call's first pair in the sweep (rotation of the K walks)
                                 const float* dcache_l = nullptr);   // Delta cache rows of the left pool (ovn_delta_cache), 1-vs-N only
 int ovn_delta_cache_forward(ovn_ctx* ctx, const float* feats, int n, float* cache, hipStream_t stream);
+
+// delta_head_generic.hip: the Delta head for any conv1size (fp32, generality path)
+size_t ovn_delta_generic_pair_bytes(int G);
+int ovn_delta_generic_forward(const ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
+                              const int32_t* ridx, int n, void* scratch, float* overlap, float* logit, hipStream_t stream);
 
 // corr_head.hip
 int ovn_corr_forward(const float* feats_l, const int32_t* lidx, const float* feats_r, const int32_t* ridx,

@@ -46,6 +46,7 @@ class OvnEngine:
         self._head_ready = False
         self.head_precision = "f16x3"
         self.leg_precision = "f16x3"
+        self.conv1size = 15
         self.check_device_indices = False    # opt-in range check of pair-index tensors that already live on the device (_idx)
 
     # -- lifetime -----------------------------------------------------------------------------------
@@ -69,8 +70,7 @@ class OvnEngine:
         """Register leg + head weights given by Keras layer name (reference infer.py:117-120)."""
         cfg = model_cfg or {}
         W.check_weights(weights, self.in_c, cfg)
-        if int(cfg.get("conv1NetworkHead_conv1size", 15)) != 15:
-            raise _lib.OvnError("the HIP Delta head is built for conv1NetworkHead_conv1size=15 (the reference default)")
+        self.conv1size = int(cfg.get("conv1NetworkHead_conv1size", 15))     # generateNet.py:88-89
         with torch.cuda.device(self.device):
             st = self._stream()
             for l in W.leg_layers(self.in_c, cfg):
@@ -82,6 +82,8 @@ class OvnEngine:
             _lib.check(self.lib.ovn_finalize(self._h, C.byref(fw)), "ovn_finalize")
             self.feat_w = fw.value
             self._leg_ready = True
+            if self.conv1size != 15:   # any other value: the library's general fp32 Delta path (no Delta cache)
+                _lib.check(self.lib.ovn_set_head_geometry(self._h, self.conv1size), "ovn_set_head_geometry")
             names = ["c_conv1", "c_conv2", "c_conv3", "overlap_output"]
             ts = []
             for n in names:
@@ -227,11 +229,17 @@ class OvnEngine:
     SPEC_W = 368
     DELTA_CACHE_ELEMS = 49216      # floats per Delta cache row (include/ovn_hip.h: OVN_DELTA_CACHE_ELEMS)
 
+    @property
+    def has_delta_cache(self) -> bool:
+        return self.conv1size == 15
+
     def delta_cache(self, feats: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """feature volumes (n,360,128) -> Delta cache rows (n, 49216): the candidate-side half of the Delta head's preparation
         (packed words, TT + b2, value range), cached next to the volume like its spectrum."""
         if not self._head_ready:
             raise _lib.OvnError("head weights not loaded")
+        if not self.has_delta_cache:
+            raise _lib.OvnError("the Delta cache exists for conv1NetworkHead_conv1size=15 only")
         self._check_feats(feats, "feats")
         n = feats.numel() // (FEAT_W * FEAT_C)
         if out is None:

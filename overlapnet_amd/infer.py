@@ -54,15 +54,17 @@ class FeatureVolumeCache(object):
       dev = self._engine.device
       nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
       ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
-      nd = torch.empty((cap, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
+      nd = torch.empty((cap if self._engine.has_delta_cache else 0, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
       if self._n:
         nf[:self._n].copy_(self._fv[:self._n])
         ns[:self._n].copy_(self._spec[:self._n])
-        nd[:self._n].copy_(self._dc[:self._n])
+        if self._engine.has_delta_cache:
+          nd[:self._n].copy_(self._dc[:self._n])
       self._fv, self._spec, self._dc = nf, ns, nd
     self._fv[self._n:self._n + k].copy_(fv)
     self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
-    self._engine.delta_cache(self._fv[self._n:self._n + k], out=self._dc[self._n:self._n + k])
+    if self._engine.has_delta_cache:
+      self._engine.delta_cache(self._fv[self._n:self._n + k], out=self._dc[self._n:self._n + k])
     self._n += k
 
   @property
@@ -74,7 +76,10 @@ class FeatureVolumeCache(object):
     return self._spec[:self._n] if self._spec is not None else torch.empty((0, FEAT_C, self._engine.SPEC_W), device=self._engine.device)
 
   @property
-  def device_delta_cache(self) -> torch.Tensor:
+  def device_delta_cache(self) -> Optional[torch.Tensor]:
+    """Delta cache rows of the cached volumes, or None when the head geometry has none (conv1size != 15)."""
+    if not self._engine.has_delta_cache:
+      return None
     return self._dc[:self._n] if self._dc is not None else torch.empty((0, self._engine.DELTA_CACHE_ELEMS), device=self._engine.device)
 
   # -- list / ndarray behaviour ----------------------------------------------------------------------

@@ -898,3 +898,60 @@ def test_delta_cache_is_ignored_where_it_does_not_apply(engines):
         assert torch.equal(a["logit"], b["logit"])
     finally:
         e.set_head_precision(DEFAULT_HEAD)
+
+
+@pytest.mark.parametrize("s", [10, 16, 24, 40])
+def test_other_conv1sizes_run_the_general_path(s, tmp_path, fixture_npz):
+    """`conv1NetworkHead_conv1size` != 15 (generateNet.py:88-89): the library's general fp32 Delta path, against the fp64 oracle built
+    with the same s -- s = 16 and 40 do not divide 360 ('valid' convolutions drop the remainder: 22 and 9 groups) -- through the
+    engine and through `Infer` with the network.yml key."""
+    from overlapnet_amd.engine import OvnEngine
+    from overlapnet_amd.infer import Infer
+    cfg = dict(CFG, conv1NetworkHead_conv1size=s)
+    w = S.make_test_weights(4, seed=3, model_cfg=cfg)
+    g = 360 // s
+    assert w["c_conv1/kernel"].shape == (1, s, 128, 64) and w["overlap_output/kernel"].shape == ((g - 2) ** 2 * 256, 1)
+    rng = np.random.default_rng(1000 + s)
+    fv = np.maximum(rng.normal(0.2, 1.0, size=(6, 360, 128)), 0).astype(np.float32)
+    fv[4] = -fv[4]                                  # signed features too
+    pairs = np.array([[0, 1], [1, 0], [2, 2], [3, 5], [4, 0], [5, 4], [0, 3]])
+    e = OvnEngine(64, 900, 4)
+    try:
+        e.load_weights(w, cfg)
+        assert e.conv1size == s and not e.has_delta_cache
+        ft = torch.from_numpy(fv).cuda()
+        r = e.heads(ft, ft, lidx=pairs[:, 0], ridx=pairs[:, 1], want_logit=True)
+        spec = e.spectrum(ft)
+        r2 = e.heads(ft, ft[1:2].contiguous(), spec_l=spec, spec_r=spec[1:2].contiguous(), want_logit=True)
+        with pytest.raises(Exception, match="Delta cache"):
+            e.delta_cache(ft)
+        fv4 = fv.reshape(-1, 1, 360, 128).astype(np.float64)
+        ov, yaw, lg, _ = O.heads_forward(fv4[pairs[:, 0]], fv4[pairs[:, 1]], w, conv1size=s)
+        assert np.max(np.abs(r["overlap"].cpu().numpy() - ov)) <= 1e-4 and np.array_equal(r["yaw"].cpu().numpy(), yaw)
+        assert np.all(np.abs(r["logit"].cpu().numpy() - lg) <= 1e-3 * (1 + np.abs(lg)))
+        ov2, yaw2, lg2, _ = O.heads_forward(fv4, np.repeat(fv4[1:2], 6, axis=0), w, conv1size=s)
+        assert np.max(np.abs(r2["overlap"].cpu().numpy() - ov2)) <= 1e-4 and np.array_equal(r2["yaw"].cpu().numpy(), yaw2)
+        assert lg.max() - lg.min() > 0.5            # not a degenerate (constant) head
+    finally:
+        e.close()
+    if s == 10:                                     # the network.yml route: Infer accepts the key and streams frames as usual
+        seq = tmp_path / "data" / "07"
+        for sub in ("depth", "normal"):
+            os.makedirs(seq / sub)
+        imgs = []
+        for i in range(3):
+            d, nm = np.roll(fixture_npz["range_%d" % (i % 2)], 30 * i, axis=1), np.roll(fixture_npz["normal_%d" % (i % 2)], 30 * i, axis=1)
+            np.save(seq / "depth" / ("%06d.npy" % i), d)
+            np.save(seq / "normal" / ("%06d.npy" % i), nm)
+            imgs.append(S.stack(d, nm, None, (True, True, False)))
+        conf = {"model": dict(cfg, legsType="360OutputkLegs", overlap_head="DeltaLayerConv1NetworkHead", orientation_head="CorrelationHead",
+                              inputShape=[64, 900], leg_output_width=360),
+                "infer_seqs": "07", "data_root_folder": str(tmp_path / "data"), "use_depth": True, "use_normals": True,
+                "use_class_probabilities": False, "use_class_probabilities_pca": False, "use_intensity": False, "batch_size": 16,
+                "pretrained_weightsfilename": ""}
+        inf = Infer(conf, weights=w)
+        for i in range(3):
+            res = inf.infer_multiple(i, list(range(i)))
+        ofv = O.leg_forward(np.stack(imgs), w, cfg, np.float64)
+        o_ov, o_yaw, _, _ = O.heads_forward(ofv[[0, 1]], ofv[[2, 2]], w, conv1size=s)
+        assert np.max(np.abs(res[0] - o_ov)) <= 1e-4 and np.array_equal(res[1], o_yaw)
