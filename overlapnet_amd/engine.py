@@ -331,11 +331,13 @@ class OvnEngine:
     # -- preprocessing ------------------------------------------------------------------------------
     def project(self, points: torch.Tensor, offsets: torch.Tensor, max_points: int, proj_h: int = 64,
                 proj_w: int = 900, fov_up: float = 3.0, fov_down: float = -25.0, max_range: float = 50.0,
-                want: Sequence[str] = ("range", "normal", "intensity"), stacked_flags: Optional[Tuple[bool, bool, bool]] = None):
+                want: Sequence[str] = ("range", "normal", "intensity"), stacked_flags: Optional[Tuple[bool, bool, bool]] = None,
+                stacked_out: Optional[torch.Tensor] = None):
         """Batch spherical projection.  points: (total,4) f32 device tensor of concatenated scans,
-        offsets: (n_scans+1) int64 device tensor.  `want` selects outputs among
-        range, vertex, intensity, idx, normal; stacked_flags=(use_depth,use_normals,use_intensity)
-        additionally assembles the (n,H,W,C) leg input.  Returns a dict of device tensors."""
+        offsets: (n_scans+1) int64 device tensor (absolute positions in `points`: a slice of a longer offsets tensor projects
+        that range of scans).  `want` selects outputs among range, vertex, intensity, idx, normal;
+        stacked_flags=(use_depth,use_normals,use_intensity) additionally assembles the (n,H,W,C) leg input (into `stacked_out`
+        when given).  Returns a dict of device tensors."""
         if points.device != self.device or points.dtype != torch.float32 or not points.is_contiguous():
             raise _lib.OvnError("points must be a contiguous float32 tensor on %s" % self.device)
         if offsets.device != self.device or offsets.dtype != torch.int64:
@@ -353,7 +355,14 @@ class OvnEngine:
         ud = un = ui = 0
         if stacked_flags is not None:
             ud, un, ui = (int(bool(v)) for v in stacked_flags)
-            stk = mk(n, proj_h, proj_w, ud + 3 * un + ui)
+            if stacked_out is not None:
+                if (stacked_out.device != self.device or stacked_out.dtype != torch.float32 or not stacked_out.is_contiguous()
+                        or tuple(stacked_out.shape) != (n, proj_h, proj_w, ud + 3 * un + ui)):
+                    raise _lib.OvnError("stacked_out must be a contiguous float32 (%d,%d,%d,%d) tensor on %s"
+                                        % (n, proj_h, proj_w, ud + 3 * un + ui, self.device))
+                stk = stacked_out
+            else:
+                stk = mk(n, proj_h, proj_w, ud + 3 * un + ui)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ovn_project(self._h, _ptr(points), _ptr(offsets), n, int(max_points), proj_h, proj_w,
                                             float(fov_up), float(fov_down), float(max_range), _ptr(rng), _ptr(vtx),
