@@ -154,3 +154,24 @@ def test_delta_head_literal_at_full_size():
     # correlation head, literal padded sliding window at full size vs the Gram-diagonal closed form
     corr = O.correlation_head_forward(fl, fr)
     np.testing.assert_allclose(corr, O.correlation_literal(fl, fr).reshape(1, 360), rtol=1e-11, atol=1e-9)
+
+
+def test_oracle_convolution_against_scipy():
+    """Third implementation of the one primitive the neural oracle stands on: Keras `Conv2D(padding='valid')` is a cross-correlation
+    (no kernel flip) sub-sampled by the stride.  The oracle's fast form (torch conv2d) and its literal NumPy form are compared with
+    scipy.signal.correlate on the layer shapes the leg and the head use (strides (2,2), (2,1), (1,s), (s,1))."""
+    import torch
+    from scipy.signal import correlate
+    rng = np.random.default_rng(11)
+    for (h, w, cin, cout, kh, kw, sh, sw) in ((11, 37, 4, 3, 5, 15, 2, 2), (9, 40, 3, 5, 3, 15, 2, 1), (1, 30, 6, 4, 1, 9, 1, 1),
+                                              (12, 30, 2, 3, 1, 15, 1, 15), (30, 4, 3, 2, 15, 1, 15, 1), (8, 8, 5, 7, 3, 3, 1, 1)):
+        x = rng.normal(size=(h, w, cin))
+        k = rng.normal(size=(kh, kw, cin, cout))
+        b = rng.normal(size=cout)
+        want = np.stack([sum(correlate(x[:, :, c], k[:, :, c, o], mode="valid") for c in range(cin)) + b[o] for o in range(cout)], axis=-1)
+        want = want[::sh, ::sw]
+        fast = O._conv_valid(torch.from_numpy(x).permute(2, 0, 1)[None], k, b, (sh, sw), False, torch.float64)[0].permute(1, 2, 0).numpy()
+        lit = O.conv2d_valid_literal(x, k, b, (sh, sw), relu=False)
+        assert fast.shape == want.shape == lit.shape == ((h - kh) // sh + 1, (w - kw) // sw + 1, cout)
+        np.testing.assert_allclose(fast, want, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(lit, want, rtol=1e-12, atol=1e-12)
