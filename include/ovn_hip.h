@@ -154,7 +154,9 @@ int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec
  * Defaults: 1024, 0, 1, 0 -- the serial order.  Measured on MI355X (profiles/r3a_pipeline_matrix.md): the contraction kernel
  * occupies every CU completely (256 registers x 8 waves, 126 KB of LDS), so kernels of a second stream only run in the gaps
  * between its workgroups and none of the forked forms is faster than the serial one; the knobs remain for sweeps whose
- * kernels leave room.  Results do not depend on any of these (every pair is computed by the same kernels with per-pair scales). */
+ * kernels leave room.  Results do not depend on any of these (every pair is computed by the same kernels with per-pair scales).
+ * (For experiments the environment variables OVN_HEAD_CHUNK, OVN_HEAD_SUBCHUNK, OVN_HEAD_STREAMS and OVN_YAW_SIDE preset the four
+ * values when a context is created; tools/experiments/r3_pipeline_matrix.sh.) */
 int ovn_set_head_pipeline(ovn_ctx* ctx, int64_t chunk_pairs, int64_t sub_chunk_pairs, int streams, int yaw_on_side_stream);
 /* The current settings (any output pointer may be NULL). */
 int ovn_get_head_pipeline(ovn_ctx* ctx, int64_t* chunk_pairs, int64_t* sub_chunk_pairs, int* streams, int* yaw_on_side_stream);

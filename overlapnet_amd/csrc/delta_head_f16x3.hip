@@ -910,8 +910,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 // Epilogue: acc / (s1r sw2) + TT[ib] + AA[jb] + b2, ReLU, per-pair maximum.
 __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __restrict__ o1raw, const _Float16* __restrict__ w2p,
                                                                          const DeltaDesc* __restrict__ desc, const f32x4* __restrict__ scales,
-                                                                         float* __restrict__ o2, unsigned* __restrict__ o2max, float one,
-                                                                         int total_rows) {
+                                                                         float* __restrict__ o2, unsigned* __restrict__ o2max, float one) {
   __shared__ __attribute__((aligned(16))) unsigned char wb[2][16384];
   constexpr int NKS = K2 / 32;   // 30
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1125,7 +1124,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     OvnProfScope ps(ctx, OVN_K_DELTA_C2, stream);
     const int total_rows = n * G * G;
     hipLaunchKernelGGL(delta_c2_f16x3_kernel, dim3(total_rows / C2_TILE_ROWS), dim3(256), 0, stream, o1raw,
-                       reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f, total_rows);
+                       reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f);
   }
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
