@@ -144,7 +144,7 @@ int ovn_heads_spectral(ovn_ctx* ctx, const float* feats_l_dev, const float* spec
 
 /* Launch structure of the head calls (the reference's counterpart is `batch_size`, network.yml:41, which sets how many pairs one
  * predict step materialises):
- *   chunk_pairs          pairs per pass over the context's scratch (default 1024).  The f16x3 Delta path needs 3.2 MB of scratch
+ *   chunk_pairs          pairs per pass over the context's scratch (default 1024).  The f16x3 Delta path needs 2.9 MB of scratch
  *                        per pair of a chunk (packed volumes, linear terms, the c_conv1 rows between its two kernels):
  *                        ovn_workspace_bytes ~ 3.3 GB at the default; a sweep longer than a chunk is processed in several passes;
  *   sub_chunk_pairs      0 = none; otherwise every chunk is cut into sub-chunks of this many pairs whose kernel chains
