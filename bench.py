@@ -404,6 +404,8 @@ def main():
                      "frac": achieved / peak, "traffic": rocprof_traffic(kprefix),
                      "flop_per_launch": flop_per_pair * launch_pairs, "pairs_per_launch": launch_pairs,
                      "avg_launch_ms": avg_ms,
+                     "mfma_flops_per_algorithmic_flop": 3 if args.head_precision == "f16x3" else 1,
+                     "frac_executed": (3 if args.head_precision == "f16x3" else 1) * achieved / peak,
                      "delta_total_ms": sum(prof[k][0] / max(prof[k][1], 1) for k in ("delta_prep", "delta_c12", "delta_c2") if k in prof),
                      "note": rl_note},
         "kernels": kernel_table(prof),
