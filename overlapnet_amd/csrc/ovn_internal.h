@@ -274,6 +274,11 @@ bool ovn_conv_strip_own_scale(const OvnConvLayer& L, long long call_nb, int h, i
 int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out,
                        const unsigned* in_max, unsigned* out_max, hipStream_t stream);
 
+// leg_front.hip: s_conv1 + s_conv2 of the C = 4 network fused (f16x3): the 850 KB activation between them stays in LDS
+bool ovn_leg_front_matches(const ovn_ctx* ctx, size_t first, int h, int w);
+int ovn_leg_front_forward(const ovn_ctx* ctx, size_t first, const float* in, int nb, int h, int w, float* out, int* oh_out, int* ow_out,
+                          unsigned* out_max, hipStream_t stream);
+
 // leg_tail.hip: the last six leg layers (1 x {9,9,9,7,5,3}, 128 -> 128) fused, activations carried through LDS (f16x3, batched calls)
 bool ovn_leg_tail_matches(const ovn_ctx* ctx, size_t first, int h, int w);
 int ovn_leg_tail_forward(const ovn_ctx* ctx, size_t first, const float* in, int nb, int w, float* out, hipStream_t stream);
