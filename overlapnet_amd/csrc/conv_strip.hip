@@ -10,8 +10,8 @@
 // Strip layout: one plane per group of 8 channels, [pixel][8 fp16 = 16 B], planes a multiple of 256 B apart: the 16
 // lanes that ds_read_b128 services together (8 lanes of channel group g, 8 of g+1, consecutive pixels) then cover all 64
 // banks exactly once (a pixel-major layout with any padding gives 2-way conflicts).  No barrier in the K loop (KH x KW x
-// CIN/32 steps of 32 channels, exactly the chunk order of the pre-split weights [kc][nt][hi,lo][lane][8]).  8 waves = NT
-// n-tiles x 8/NT groups of m-tiles; weight fragments straight from L2 three steps deep; A fragments for step s+1 are read
+// CIN/32 steps of 32 channels, exactly the chunk order of the pre-split weights [kc][nt][hi,lo][lane][8]).  NW (8 or 4) waves = NT
+// n-tiles x NW/NT groups of m-tiles; weight fragments straight from L2 three steps deep; A fragments for step s+1 are read
 // while step s feeds the matrix pipe.  Same per-accumulator summation order as the generic kernel: bit-identical results.
 #include <stdlib.h>
 
@@ -22,6 +22,12 @@
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// STRIP_ABL (timing-only builds of tools/experiments/strip_ablate.sh, never the product): 1 no strip staging at all, 2 no K loop,
+// 4 staging without the global loads (split + LDS writes of constants)
+#ifndef STRIP_ABL
+#define STRIP_ABL 0
+#endif
 
 namespace {
 
@@ -36,22 +42,24 @@ struct StripArgs {
   int H, W, OH, OW, XT;   // input rows / cols, output rows / cols, x tiles per output row
 };
 
-template <int CIN, int KH, int KW, int TW, int NT>
+template <int CIN, int KH, int KW, int TW, int NT, int NW = 8>
 struct StripCfg {
   static constexpr int PIX = TW + KW - 1;              // input pixels per strip row
   static constexpr int PLANE = (KH * PIX * 8 + 127) / 128 * 128;  // fp16 elements per 8-channel plane (multiple of 256 B)
   static constexpr int NPL = CIN / 8;                  // planes
   static constexpr int MT = (TW + 15) / 16;            // m-tiles per workgroup
-  static constexpr int MSPLIT = 8 / NT;                // wave groups along M (8 waves = NT n-tiles x MSPLIT)
+  static constexpr int MSPLIT = NW / NT;               // wave groups along M (NW waves = NT n-tiles x MSPLIT)
   static constexpr int MTH = (MT + MSPLIT - 1) / MSPLIT;   // m-tiles per wave
   static constexpr int CC = CIN / 32;                  // 32-channel chunks per tap
   static constexpr int NK = KH * KW * CC;              // K steps
   static constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 1024;   // + slack for padded-row reads
 };
 
-template <int CIN, int KH, int SH, int KW, int TW, int NT>
-__global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
-  typedef StripCfg<CIN, KH, KW, TW, NT> C;
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_strip_kernel(StripArgs a) {
+  typedef StripCfg<CIN, KH, KW, TW, NT, NW> C;
+  constexpr int NTHR = 64 * NW;
+  static_assert(NW % NT == 0, "waves = n-tiles x groups of m-tiles");
   constexpr int COUT = 16 * NT;
   constexpr int PLANE = C::PLANE, PIX = C::PIX, MTH = C::MTH, CC = C::CC, NK = C::NK;
   extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
@@ -82,10 +90,10 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   const float inv = 1.0f / (s_in * a.sw);
 
   // ---- strip -> LDS, split once ----
-  {
+  if (!(STRIP_ABL & 1)) {
     constexpr int Q = CIN / 4;                                // float4 groups per pixel
     constexpr int TOTAL = KH * PIX * Q;
-    constexpr int ITERS = (TOTAL + 511) / 512;
+    constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;
     // all loads of a batch are issued before the first is consumed (a rolled loop would pay one memory round trip
     // per iteration: the compiler cannot overlap iterations it does not see)
     constexpr int BATCH = 6;
@@ -94,19 +102,20 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
       f32x4 v[BATCH];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int i = tid + (it0 + u) * 512;
+        const int i = tid + (it0 + u) * NTHR;
         v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (i < TOTAL) {
           const int row = i / (PIX * Q);
           const int r = i - row * (PIX * Q);
           const int pix = r / Q;
           const int c = 4 * (r - pix * Q);
-          if (pix < pixv) v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + x0 + pix) * CIN + c);
+          if (STRIP_ABL & 4) v[u] = (f32x4){a.one, a.sw, a.one, a.sw};
+          else if (pix < pixv) v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + x0 + pix) * CIN + c);
         }
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int i = tid + (it0 + u) * 512;
+        const int i = tid + (it0 + u) * NTHR;
         if (i < TOTAL) {
           const int row = i / (PIX * Q);
           const int r = i - row * (PIX * Q);
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(512) void conv_strip_kernel(StripArgs a) {
   __syncthreads();  // strip complete
   STRIP_READ_A(0, 0)
   // fully unrolled K walk (compile-time k): 3 weight slots x 2 fragment buffers, everything one step (A) / two steps (B) ahead
-  [&]<int... K>(std::integer_sequence<int, K...>) {
+  if (!(STRIP_ABL & 2)) [&]<int... K>(std::integer_sequence<int, K...>) {
     (([&] {
        if constexpr (K + 2 < NK) STRIP_LOAD_B((K + 2) % 3, K + 2)
        if constexpr (K + 1 < NK) STRIP_READ_A((K + 1) & 1, K + 1)
@@ -413,10 +422,10 @@ int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long
   return OVN_OK;
 }
 
-template <int CIN, int KH, int SH, int KW, int TW, int NT>
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW = 8>
 int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out, const unsigned* in_max,
                  unsigned* out_max, hipStream_t stream, bool* took) {
-  typedef StripCfg<CIN, KH, KW, TW, NT> C;
+  typedef StripCfg<CIN, KH, KW, TW, NT, NW> C;
   StripArgs a;
   a.in = in;
   a.wp = reinterpret_cast<const _Float16*>(L.wp_h);
@@ -433,9 +442,9 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_
   a.XT = (a.OW + TW - 1) / TW;
   const long long wgs = (long long)nb * a.OH * a.XT;
   *took = true;   // every call size takes this kernel (one scan: OH x XT workgroups, still faster than the generic kernel's serial K walk)
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), C::LDS_BYTES);
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT, NW>), C::LDS_BYTES);
   if (rc) return rc;
-  hipLaunchKernelGGL((conv_strip_kernel<CIN, KH, SH, KW, TW, NT>), dim3((unsigned)wgs), dim3(512), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_strip_kernel<CIN, KH, SH, KW, TW, NT, NW>), dim3((unsigned)wgs), dim3(64 * NW), C::LDS_BYTES, stream, a);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -475,8 +484,11 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
   if (L.kh > 1 && L.sh != 2) return 0;
   if (L.kh == 1 && L.sh != 1) return 0;
   switch (key) {
-    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 208, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3
-    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 135, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3a
+    // s_conv3 / s_conv3a: workgroups of FOUR waves (one per n-tile, all m-tiles of a narrow tile each) -- three / two of them share a CU,
+    // so one stages or stores while another is in its K loop (the 8-wave, one-per-CU tiles of 208 / 135 pixels: +3 % leg time;
+    // same K order per accumulator, identical bits)
+    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 104, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3
+    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 64, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;    // s_conv3a
     // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
     case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
       rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)

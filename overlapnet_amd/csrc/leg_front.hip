@@ -74,6 +74,24 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
   const int iy0 = S1 * oy1, ix0 = S1 * x0;     // first input row / pixel
   const int pixv = (a.W - ix0 < PIXA1) ? a.W - ix0 : PIXA1;
 
+  // weight fragments travel three K steps ahead of their MFMAs (an L2 round trip is longer than one step); the first steps of
+  // stage A are requested before the strip, those of stage B before stage A's epilogue
+  f16x8 bq[3][2];
+  const _Float16* wbase1 = a.wp1 + lane * 8;
+  const _Float16* wbase2 = a.wp2 + (size_t)__builtin_amdgcn_readfirstlane(wave & 1) * (2 * 512) + lane * 8;
+#define FRONT_LOAD_B1(SLOT, KS)                                                              \
+  {                                                                                          \
+    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(wbase1 + (size_t)(KS) * (2 * 512));        \
+    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(wbase1 + (size_t)(KS) * (2 * 512) + 512);  \
+  }
+#define FRONT_LOAD_B2(SLOT, KS)                                                                  \
+  {                                                                                              \
+    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(wbase2 + (size_t)(KS) * (2 * 2 * 512));        \
+    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(wbase2 + (size_t)(KS) * (2 * 2 * 512) + 512);  \
+  }
+  FRONT_LOAD_B1(0, 0)
+  FRONT_LOAD_B1(1, 1)
+
   // ---- input strip -> LDS, scaled by its own maximum and split once (zero outside the image) ----
   float s_in;
   {
@@ -137,13 +155,12 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
     f32x4 acc[MTHA];
 #pragma unroll
     for (int i = 0; i < MTHA; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const _Float16* wbase = a.wp1 + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < NKA; ++ks) {
       const int ky = ks >> 1, kh = ks & 1;
       const int toff = (ky * PIXA1 + 8 * kh) * C0;
-      const f16x8 bh = *reinterpret_cast<const f16x8*>(wbase + (size_t)ks * (2 * 512));
-      const f16x8 bl = *reinterpret_cast<const f16x8*>(wbase + (size_t)ks * (2 * 512) + 512);
+      if (ks + 2 < NKA) FRONT_LOAD_B1((ks + 2) % 3, ks + 2)
+      const f16x8 bh = bq[ks % 3][0], bl = bq[ks % 3][1];
       f16x8 fh[MTHA], fl[MTHA];
 #pragma unroll
       for (int i = 0; i < MTHA; ++i) {
@@ -157,6 +174,8 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
 #pragma unroll
       for (int i = 0; i < MTHA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bl, acc[i], 0, 0, 0);
     }
+    FRONT_LOAD_B2(0, 0)
+    FRONT_LOAD_B2(1, 1)
     // bias + ReLU; positions outside the s_conv1 image are zero (finite, and out of the tile maximum)
     const float inv = 1.0f / (s_in * a.sw1);
     const float bv = a.b1[lrow];
@@ -221,13 +240,12 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
     f32x4 acc[MTHB];
 #pragma unroll
     for (int i = 0; i < MTHB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const _Float16* wbase = a.wp2 + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512) + lane * 8;
 #pragma unroll
     for (int ks = 0; ks < NKB; ++ks) {
       const int ky = ks >> 3, kh = ks & 7;
       const int toff = (ky * PIXM + 2 * kh) * C1;
-      const f16x8 bh = *reinterpret_cast<const f16x8*>(wbase + (size_t)ks * (2 * 2 * 512));
-      const f16x8 bl = *reinterpret_cast<const f16x8*>(wbase + (size_t)ks * (2 * 2 * 512) + 512);
+      if (ks + 2 < NKB) FRONT_LOAD_B2((ks + 2) % 3, ks + 2)
+      const f16x8 bh = bq[ks % 3][0], bl = bq[ks % 3][1];
       f16x8 fh[MTHB], fl[MTHB];
 #pragma unroll
       for (int i = 0; i < MTHB; ++i) {
@@ -263,6 +281,9 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
     if (a.out_max) ovn_fold_absmax_wg(vmax, a.out_max + (size_t)b * OVN_ACTMAX_STRIDE, wg_red);   // kernel-uniform condition
   }
 }
+
+#undef FRONT_LOAD_B1
+#undef FRONT_LOAD_B2
 
 bool is_layer(const OvnConvLayer& L, int kh, int kw, int cin, int cout, int sh, int sw) {
   return L.relu && L.kh == kh && L.kw == kw && L.cin == cin && L.cout == cout && L.sh == sh && L.sw == sw && L.wp_h16 != nullptr;

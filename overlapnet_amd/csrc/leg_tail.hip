@@ -50,11 +50,26 @@ __device__ __forceinline__ void split2(float x0, float x1, float one, _Float16& 
   l1 = (_Float16)__builtin_fmaf(x1, one, -(float)hp[1]);
 }
 
+// K steps 0 .. 3 of a layer's weights -> ring slots 0 .. 3 (n-tiles 2 wn, 2 wn + 1 of this wave)
+__device__ __forceinline__ void tail_preload(f16x8 (&bq)[5][2][2], const _Float16* __restrict__ wp) {
+  const int lane = threadIdx.x & 63, wn = (threadIdx.x >> 6) & 3;
+  const _Float16* wbase = wp + (size_t)(2 * wn) * (2 * 512) + lane * 8;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const _Float16* q = wbase + (size_t)ks * (8 * 2 * 512);
+    bq[ks][0][0] = *reinterpret_cast<const f16x8*>(q);
+    bq[ks][0][1] = *reinterpret_cast<const f16x8*>(q + 512);
+    bq[ks][1][0] = *reinterpret_cast<const f16x8*>(q + 1024);
+    bq[ks][1][1] = *reinterpret_cast<const f16x8*>(q + 1536);
+  }
+}
+
 // One layer: in strip (ih, il; scaled by s_in) -> out strip (oh, ol; scaled by the returned scale) or, LAST, fp32 rows in HBM.
 template <int KW, int WOUT, bool LAST>
 __device__ __forceinline__ float tail_layer(const _Float16* __restrict__ ih, const _Float16* __restrict__ il, _Float16* __restrict__ oh,
                                             _Float16* __restrict__ ol, float* __restrict__ red, const _Float16* __restrict__ wp,
-                                            const float* __restrict__ bias, float s_in, float sw, float one, float* __restrict__ gout) {
+                                            const float* __restrict__ bias, float s_in, float sw, float one, float* __restrict__ gout,
+                                            const _Float16* __restrict__ wp_next, f16x8 (&bq)[5][2][2]) {
   constexpr int MT = (WOUT + 15) / 16;   // m-tiles of this layer's output
   constexpr int MTW = (MT + 1) / 2;      // per wave: m-tiles wm, wm + 2, ...
   constexpr int NK = KW * 4;             // K steps: tap-major, 4 chunks of 32 channels
@@ -67,7 +82,7 @@ __device__ __forceinline__ float tail_layer(const _Float16* __restrict__ ih, con
 #pragma unroll
   for (int i = 0; i < MTW; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const _Float16* wbase = wp + (size_t)(2 * wn) * (2 * 512) + lane * 8;   // n-tiles 2 wn, 2 wn + 1
-  f16x8 bq[5][2][2];        // [ring slot][n-tile][hi, lo]
+  // bq: [ring slot][n-tile][hi, lo]; slots 0 .. 3 already hold this layer's K steps 0 .. 3 (loaded by the previous layer / the kernel prologue)
   f16x8 fh[2][MTW], fl[2][MTW];
 #define TAIL_LOAD_B(SLOT, KS)                                                         \
   {                                                                                   \
@@ -85,10 +100,6 @@ __device__ __forceinline__ float tail_layer(const _Float16* __restrict__ ih, con
       fl[BUF][i] = *reinterpret_cast<const f16x8*>(al_base + toff_ + i * 256);        \
     }                                                                                 \
   }
-  TAIL_LOAD_B(0, 0)
-  TAIL_LOAD_B(1, 1)
-  TAIL_LOAD_B(2, 2)
-  TAIL_LOAD_B(3, 3)
   TAIL_READ_A(0, 0)
   [&]<int... K>(std::integer_sequence<int, K...>) {
     (([&] {
@@ -116,6 +127,9 @@ __device__ __forceinline__ float tail_layer(const _Float16* __restrict__ ih, con
   }(std::make_integer_sequence<int, NK>{});
 #undef TAIL_LOAD_B
 #undef TAIL_READ_A
+  // the next layer's first four weight steps travel while this layer's epilogue runs (its barriers would otherwise be followed by an
+  // exposed L2 round trip: six of them per workgroup)
+  if (!LAST) tail_preload(bq, wp_next);
 
   // C/D layout: lane holds channel n = 16 (2 wn + j) + lrow, pixels 16 (wm + 2 i) + 4 g + r
   const float inv = 1.0f / (s_in * sw);
@@ -200,6 +214,8 @@ __global__ __launch_bounds__(512) void leg_tail_kernel(TailArgs a) {
   constexpr int TOTAL = W0 * Q;                // 4032
   constexpr int PER = (TOTAL + 511) / 512;     // 8
   const float* src = a.in + ((size_t)b * a.win + x0) * CH;
+  f16x8 bq[5][2][2];
+  tail_preload(bq, a.wp[0]);   // ahead of the strip loads: both are in flight together
   f32x4 v[PER];
   float m = 0.f;
 #pragma unroll
@@ -235,13 +251,13 @@ __global__ __launch_bounds__(512) void leg_tail_kernel(TailArgs a) {
   __syncthreads();
 
   float s = s0;
-  s = tail_layer<K0, W1, false>(b0h, b0l, b1h, b1l, red, a.wp[0], a.bias[0], s, a.sw[0], a.one, nullptr);
-  s = tail_layer<K1, W2, false>(b1h, b1l, b0h, b0l, red, a.wp[1], a.bias[1], s, a.sw[1], a.one, nullptr);
-  s = tail_layer<K2, W3, false>(b0h, b0l, b1h, b1l, red, a.wp[2], a.bias[2], s, a.sw[2], a.one, nullptr);
-  s = tail_layer<K3, W4, false>(b1h, b1l, b0h, b0l, red, a.wp[3], a.bias[3], s, a.sw[3], a.one, nullptr);
-  s = tail_layer<K4, W5, false>(b0h, b0l, b1h, b1l, red, a.wp[4], a.bias[4], s, a.sw[4], a.one, nullptr);
+  s = tail_layer<K0, W1, false>(b0h, b0l, b1h, b1l, red, a.wp[0], a.bias[0], s, a.sw[0], a.one, nullptr, a.wp[1], bq);
+  s = tail_layer<K1, W2, false>(b1h, b1l, b0h, b0l, red, a.wp[1], a.bias[1], s, a.sw[1], a.one, nullptr, a.wp[2], bq);
+  s = tail_layer<K2, W3, false>(b0h, b0l, b1h, b1l, red, a.wp[2], a.bias[2], s, a.sw[2], a.one, nullptr, a.wp[3], bq);
+  s = tail_layer<K3, W4, false>(b1h, b1l, b0h, b0l, red, a.wp[3], a.bias[3], s, a.sw[3], a.one, nullptr, a.wp[4], bq);
+  s = tail_layer<K4, W5, false>(b0h, b0l, b1h, b1l, red, a.wp[4], a.bias[4], s, a.sw[4], a.one, nullptr, a.wp[5], bq);
   (void)tail_layer<K5, TOUT, true>(b1h, b1l, nullptr, nullptr, red, a.wp[5], a.bias[5], s, a.sw[5], a.one,
-                                   a.out + ((size_t)b * OVN_FEAT_W + x0) * CH);
+                                   a.out + ((size_t)b * OVN_FEAT_W + x0) * CH, nullptr, bq);
 }
 
 }  // namespace
