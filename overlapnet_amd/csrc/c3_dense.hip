@@ -71,6 +71,19 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   const int lrow = lane & 15;
   const int g = lane >> 4;
 
+  // weight fragments: wp[kc][nt(16)][hi,lo][lane][8], kc = tap * 4 + channel chunk; this wave's n-tiles 2w, 2w+1
+  const elem_t* wsrc = wp + ((size_t)(2 * wave) * 2) * 512 + lane * 8;
+  v8_t bq[3][4];   // weight fragments of three K steps in flight (an L2 round trip is longer than one step)
+#define C3_LOAD_B(DST, KC)                                                                  \
+  {                                                                                         \
+    const elem_t* q = wsrc + (size_t)(KC) * (16 * 2 * 512);                                 \
+    DST[0] = *reinterpret_cast<const v8_t*>(q);                                           \
+    DST[1] = *reinterpret_cast<const v8_t*>(q + 512);                                     \
+    DST[2] = *reinterpret_cast<const v8_t*>(q + 1024);                                    \
+    DST[3] = *reinterpret_cast<const v8_t*>(q + 1536);                                    \
+  }
+  C3_LOAD_B(bq[0], 0)   // requested ahead of the patch: both round trips overlap
+  C3_LOAD_B(bq[1], 1)
   const float s2 = ovn_pow2_scale_for(__uint_as_float(o2max[pair]));
   const float inv = 1.0f / (s2 * sw3);
   // ---- input patch -> LDS, split once (x * s2 = hi + lo, both 16-bit, round to nearest) ----
@@ -124,17 +137,6 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
     acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  // weight fragments: wp[kc][nt(16)][hi,lo][lane][8], kc = tap * 4 + channel chunk; this wave's n-tiles 2w, 2w+1
-  const elem_t* wsrc = wp + ((size_t)(2 * wave) * 2) * 512 + lane * 8;
-  v8_t bq[3][4];   // weight fragments of three K steps in flight (an L2 round trip is longer than one step)
-#define C3_LOAD_B(DST, KC)                                                                  \
-  {                                                                                         \
-    const elem_t* q = wsrc + (size_t)(KC) * (16 * 2 * 512);                                 \
-    DST[0] = *reinterpret_cast<const v8_t*>(q);                                           \
-    DST[1] = *reinterpret_cast<const v8_t*>(q + 512);                                     \
-    DST[2] = *reinterpret_cast<const v8_t*>(q + 1024);                                    \
-    DST[3] = *reinterpret_cast<const v8_t*>(q + 1536);                                    \
-  }
 // m-tiles go two at a time and term-major, so that consecutive MFMAs never chain on one accumulator (4 apart)
 #define C3_MFMA2(M0, M1, A0H, A0L, A1H, A1L, SRC)                                                  \
   acc[M0][0] = A::mfma(A0H, SRC[0], acc[M0][0]);          \
@@ -183,8 +185,6 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
       acc[MAX_MT - 1][1] = A::mfma(ah, SRC[3], acc[MAX_MT - 1][1]); \
     }                                                                                       \
   }
-  C3_LOAD_B(bq[0], 0)
-  C3_LOAD_B(bq[1], 1)
   __syncthreads();  // patch complete
 #pragma unroll 1
   for (int kc = 0; kc < 36; kc += 3) {

@@ -55,8 +55,11 @@ struct StripCfg {
   static constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 1024;   // + slack for padded-row reads
 };
 
-template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW>
-__global__ __launch_bounds__(64 * NW) void conv_strip_kernel(StripArgs a) {
+// WPS: waves per SIMD the register budget must allow; with WPS 4 (128 registers) the A fragments are read at their own step instead of
+// one step ahead (the other waves of the SIMD cover the LDS round trip)
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW, int WPS>
+__global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
+  constexpr int ABUF = WPS >= 4 ? 1 : 2;
   typedef StripCfg<CIN, KH, KW, TW, NT, NW> C;
   constexpr int NTHR = 64 * NW;
   static_assert(NW % NT == 0, "waves = n-tiles x groups of m-tiles");
@@ -88,6 +91,19 @@ __global__ __launch_bounds__(64 * NW) void conv_strip_kernel(StripArgs a) {
   // what else is in the batch
   const float s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[(size_t)b * OVN_ACTMAX_STRIDE]));
   const float inv = 1.0f / (s_in * a.sw);
+
+  // weights [kc][nt(NT)][hi,lo][lane][8]: wave-uniform base (scalar) + one per-lane offset
+  const _Float16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512);
+  const int wlane = lane * 8;
+  f16x8 bq[3][2];
+#define STRIP_LOAD_B(SLOT, KS)                                                     \
+  {                                                                                \
+    const _Float16* q = wbase + (size_t)(KS) * (NT * 2 * 512);                       \
+    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(q + wlane);                     \
+    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(q + 512 + wlane);               \
+  }
+  STRIP_LOAD_B(0, 0)   // requested ahead of the strip: both round trips overlap
+  STRIP_LOAD_B(1, 1)
 
   // ---- strip -> LDS, split once ----
   if (!(STRIP_ABL & 1)) {
@@ -149,17 +165,7 @@ __global__ __launch_bounds__(64 * NW) void conv_strip_kernel(StripArgs a) {
 #pragma unroll
   for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // weights [kc][nt(NT)][hi,lo][lane][8]: wave-uniform base (scalar) + one per-lane offset
-  const _Float16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wn) * (2 * 512);
-  const int wlane = lane * 8;
-  f16x8 bq[3][2];
-  f16x8 fh[2][MTH], fl[2][MTH];
-#define STRIP_LOAD_B(SLOT, KS)                                                     \
-  {                                                                                \
-    const _Float16* q = wbase + (size_t)(KS) * (NT * 2 * 512);                       \
-    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(q + wlane);                     \
-    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(q + 512 + wlane);               \
-  }
+  f16x8 fh[ABUF][MTH], fl[ABUF][MTH];
 #define STRIP_READ_A(BUF, KS)                                                      \
   {                                                                                \
     constexpr int tap_ = (KS) / CC;                                                \
@@ -177,17 +183,19 @@ __global__ __launch_bounds__(64 * NW) void conv_strip_kernel(StripArgs a) {
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
   _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[BUF][i], bq[SLOT][1], acc[i], 0, 0, 0);
-  STRIP_LOAD_B(0, 0)
-  STRIP_LOAD_B(1, 1)
   __syncthreads();  // strip complete
-  STRIP_READ_A(0, 0)
+  if (ABUF == 2) STRIP_READ_A(0, 0)
   // fully unrolled K walk (compile-time k): 3 weight slots x 2 fragment buffers, everything one step (A) / two steps (B) ahead
   if (!(STRIP_ABL & 2)) [&]<int... K>(std::integer_sequence<int, K...>) {
     (([&] {
        if constexpr (K + 2 < NK) STRIP_LOAD_B((K + 2) % 3, K + 2)
-       if constexpr (K + 1 < NK) STRIP_READ_A((K + 1) & 1, K + 1)
+       if constexpr (ABUF == 2) {
+         if constexpr (K + 1 < NK) STRIP_READ_A((K + 1) & 1, K + 1)
+       } else {
+         STRIP_READ_A(0, K)
+       }
        __builtin_amdgcn_sched_barrier(0);
-       STRIP_MFMA(K & 1, K % 3)
+       STRIP_MFMA(K & (ABUF - 1), K % 3)
        __builtin_amdgcn_sched_barrier(0);
      }()),
      ...);
@@ -422,7 +430,7 @@ int launch_strip_small(const OvnConvLayer& L, const float* in, int nb, long long
   return OVN_OK;
 }
 
-template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW = 8>
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW = 8, int WPS = 2>
 int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_nb, int h, int w, float* out, const unsigned* in_max,
                  unsigned* out_max, hipStream_t stream, bool* took) {
   typedef StripCfg<CIN, KH, KW, TW, NT, NW> C;
@@ -442,9 +450,9 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_
   a.XT = (a.OW + TW - 1) / TW;
   const long long wgs = (long long)nb * a.OH * a.XT;
   *took = true;   // every call size takes this kernel (one scan: OH x XT workgroups, still faster than the generic kernel's serial K walk)
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT, NW>), C::LDS_BYTES);
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip_kernel<CIN, KH, SH, KW, TW, NT, NW, WPS>), C::LDS_BYTES);
   if (rc) return rc;
-  hipLaunchKernelGGL((conv_strip_kernel<CIN, KH, SH, KW, TW, NT, NW>), dim3((unsigned)wgs), dim3(64 * NW), C::LDS_BYTES, stream, a);
+  hipLaunchKernelGGL((conv_strip_kernel<CIN, KH, SH, KW, TW, NT, NW, WPS>), dim3((unsigned)wgs), dim3(64 * NW), C::LDS_BYTES, stream, a);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
@@ -491,8 +499,9 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
     case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 64, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;    // s_conv3a
     // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
     case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
-      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<64, 2, 2, 9, 96, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      // 128 registers per lane: two of these 45 KB workgroups per CU (with 144 registers only one fits; 1 % of the leg)
+      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                                                                 : launch_strip<64, 2, 2, 9, 96, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 9) * 1000 + 128) * 1000 + 128:   // s_conv5-7
       rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
