@@ -17,6 +17,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// FRONT_ABL (timing-only builds of tools/experiments/front_ablate.sh, never the product): 1 strip of constants instead of the global
+// loads, 2 no stage A MFMAs, 4 no stage B MFMAs, 8 no output stores, 16 no strip staging at all, 32 no intermediate-tile exchange
+#ifndef FRONT_ABL
+#define FRONT_ABL 0
+#endif
+
 namespace {
 
 constexpr int C0 = 4, C1 = 16, C2 = 32;
@@ -32,12 +38,19 @@ constexpr int IN_ELEMS = KHS1 * PIXA1 * C0;    // 17,784 fp16 per image (hi or l
 constexpr int MID_ELEMS = R1 * PIXM * C1;      // 12,800 fp16 per image
 static_assert(2 * MID_ELEMS <= 2 * IN_ELEMS, "the intermediate tile reuses the input strip's LDS");
 constexpr size_t FRONT_LDS = 2 * (size_t)IN_ELEMS * sizeof(_Float16);   // 71,136 B: two workgroups per CU
-// stage A: 8 waves x MTHA m-tiles of the 5 x 10 s_conv1 tiles, one n-tile (16 channels)
-constexpr int MTRA = PIXM / 16, MTA = R1 * MTRA, MTHA = (MTA + 7) / 8;   // 10, 50, 7
-constexpr int NKA = KH1 * 2;                   // 10 K steps: 8 taps x 4 channels each
-// stage B: 2 n-tiles x 4 wave rows, 2 x 9 m-tiles
-constexpr int MTRB = TW2 / 16, MTB = RB * MTRB, MTHB = (MTB + 3) / 4;    // 9, 18, 5
-constexpr int NKB = KH2 * 8;                   // 24 K steps: 2 taps x 16 channels each
+// 4 waves per workgroup, two workgroups per CU (two waves per SIMD, 256 registers each):
+// stage A: a wave owns COLUMNS of the 5 x 10 s_conv1 m-tiles (columns w, w + 4, w + 8): the five output rows of a column read the
+//   same 13 input rows (row r feeds output row ry with kernel row ky = r - 2 ry), so an A fragment pair read from LDS feeds up to
+//   nine MFMAs instead of three; the 10 K steps of s_conv1's weights (8 taps x 4 channels each) stay in 80 registers
+// stage B: a wave owns m-tiles w, w + 4, .. of the 2 x 9 s_conv2 m-tiles and BOTH n-tiles: an A pair feeds six MFMAs
+constexpr int NWF = 4;                          // waves
+constexpr int NTHR = 64 * NWF;
+constexpr int MTRA = PIXM / 16;                 // 10 s_conv1 m-tile columns
+constexpr int COLS = (MTRA + NWF - 1) / NWF;    // 3 column slots per wave
+constexpr int NKA = KH1 * 2;                    // 10 K steps of stage A
+constexpr int MTRB = TW2 / 16, MTB = RB * MTRB; // 9 per row, 18 s_conv2 m-tiles
+constexpr int MTHB = (MTB + NWF - 1) / NWF;     // 5 m-tile slots per wave
+constexpr int NKB = KH2 * 8;                    // 24 K steps of stage B: 2 taps x 16 channels each
 
 struct FrontArgs {
   const float* in;          // (nb, H, W, 4)
@@ -51,7 +64,60 @@ struct FrontArgs {
   int H, W, OH1, OW1, OH2, OW2, XT;
 };
 
-__global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4 waves per SIMD = two workgroups per CU: at most 128 VGPRs
+#define FRONT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, C, 0, 0, 0)
+
+// s_conv1 for NC columns of m-tiles (c0, c0 + NWF, ..): accumulators acc[column][output row], input rows walked once
+template <int NC>
+__device__ __forceinline__ void front_stage_a(const _Float16* __restrict__ sh, const _Float16* __restrict__ sl, int c0, int lrow, int g,
+                                              const f16x8 (&wh)[NKA], const f16x8 (&wl)[NKA], f32x4 (&acc)[NC][R1]) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int ry = 0; ry < R1; ++ry) acc[c][ry] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  int cbase[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) cbase[c] = (S1 * (16 * (c0 + NWF * c) + lrow)) * C0 + 8 * g;
+#pragma unroll
+  for (int r = 0; r < KHS1; ++r) {
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+      f16x8 fh[NC], fl[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        fh[c] = *reinterpret_cast<const f16x8*>(sh + cbase[c] + (r * PIXA1 + 8 * kh) * C0);
+        fl[c] = *reinterpret_cast<const f16x8*>(sl + cbase[c] + (r * PIXA1 + 8 * kh) * C0);
+      }
+      // output rows fed by input row r: ky = r - 2 ry in [0, 5); per accumulator the K steps arrive in the order ks = 2 ky + kh
+      // ascending (r ascending) and, within a step, hi hi / lo hi / hi lo -- the order of the unfused kernel
+#pragma unroll
+      for (int ry = 0; ry < R1; ++ry) {
+        const int ky = r - S1 * ry;
+        if (ky >= 0 && ky < KH1 && !(FRONT_ABL & 2)) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c][ry] = FRONT_MFMA(fh[c], wh[2 * ky + kh], acc[c][ry]);
+        }
+      }
+#pragma unroll
+      for (int ry = 0; ry < R1; ++ry) {
+        const int ky = r - S1 * ry;
+        if (ky >= 0 && ky < KH1 && !(FRONT_ABL & 2)) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c][ry] = FRONT_MFMA(fl[c], wh[2 * ky + kh], acc[c][ry]);
+        }
+      }
+#pragma unroll
+      for (int ry = 0; ry < R1; ++ry) {
+        const int ky = r - S1 * ry;
+        if (ky >= 0 && ky < KH1 && !(FRONT_ABL & 2)) {
+#pragma unroll
+          for (int c = 0; c < NC; ++c) acc[c][ry] = FRONT_MFMA(fh[c], wl[2 * ky + kh], acc[c][ry]);
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NTHR, 2) void leg_front_kernel(FrontArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char front_smem[];
   __shared__ float wg_red[16];
   _Float16* sh = reinterpret_cast<_Float16*>(front_smem);
@@ -74,37 +140,31 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
   const int iy0 = S1 * oy1, ix0 = S1 * x0;     // first input row / pixel
   const int pixv = (a.W - ix0 < PIXA1) ? a.W - ix0 : PIXA1;
 
-  // weight fragments travel three K steps ahead of their MFMAs (an L2 round trip is longer than one step); the first steps of
-  // stage A are requested before the strip, those of stage B before stage A's epilogue
-  f16x8 bq[3][2];
-  const _Float16* wbase1 = a.wp1 + lane * 8;
-  const _Float16* wbase2 = a.wp2 + (size_t)__builtin_amdgcn_readfirstlane(wave & 1) * (2 * 512) + lane * 8;
-#define FRONT_LOAD_B1(SLOT, KS)                                                              \
-  {                                                                                          \
-    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(wbase1 + (size_t)(KS) * (2 * 512));        \
-    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(wbase1 + (size_t)(KS) * (2 * 512) + 512);  \
+  // s_conv1's weights: all 10 K steps, requested before the strip (both round trips overlap)
+  f16x8 wh[NKA], wl[NKA];
+  {
+    const _Float16* wbase1 = a.wp1 + lane * 8;
+#pragma unroll
+    for (int ks = 0; ks < NKA; ++ks) {
+      wh[ks] = *reinterpret_cast<const f16x8*>(wbase1 + (size_t)ks * (2 * 512));
+      wl[ks] = *reinterpret_cast<const f16x8*>(wbase1 + (size_t)ks * (2 * 512) + 512);
+    }
   }
-#define FRONT_LOAD_B2(SLOT, KS)                                                                  \
-  {                                                                                              \
-    bq[SLOT][0] = *reinterpret_cast<const f16x8*>(wbase2 + (size_t)(KS) * (2 * 2 * 512));        \
-    bq[SLOT][1] = *reinterpret_cast<const f16x8*>(wbase2 + (size_t)(KS) * (2 * 2 * 512) + 512);  \
-  }
-  FRONT_LOAD_B1(0, 0)
-  FRONT_LOAD_B1(1, 1)
 
   // ---- input strip -> LDS, scaled by its own maximum and split once (zero outside the image) ----
-  float s_in;
-  {
+  float s_in = 1.0f;
+  if (!(FRONT_ABL & 16)) {
     constexpr int TOTAL = KHS1 * PIXA1;        // one float4 (4 channels) per pixel
-    constexpr int ITERS = (TOTAL + 511) / 512; // 9
+    constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;   // 18
     f32x4 v[ITERS];
 #pragma unroll
     for (int u = 0; u < ITERS; ++u) {
-      const int i = tid + u * 512;
+      const int i = tid + u * NTHR;
       v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (i < TOTAL) {
         const int row = i / PIXA1, pix = i - row * PIXA1;
-        if (pix < pixv && iy0 + row < a.H)
+        if (FRONT_ABL & 1) v[u] = (f32x4){a.one, a.sw1, a.one, a.sw2};
+        else if (pix < pixv && iy0 + row < a.H)
           v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + iy0 + row) * a.W + ix0 + pix) * C0);
       }
     }
@@ -117,11 +177,11 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
     __syncthreads();
     m = wg_red[0];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) m = fmaxf(m, wg_red[w]);
+    for (int w = 1; w < NWF; ++w) m = fmaxf(m, wg_red[w]);
     s_in = ovn_pow2_scale_for(m);
 #pragma unroll
     for (int u = 0; u < ITERS; ++u) {
-      const int i = tid + u * 512;
+      const int i = tid + u * NTHR;
       if (i < TOTAL) {
         f16x4 h, l;
 #pragma unroll
@@ -140,112 +200,107 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
   }
   __syncthreads();   // strip complete
 
-  // ---- stage A: s_conv1 on the 5 x 160 tile.  m-tile t = 7 wave + i: row t / 10, pixels 16 (t % 10) .. ----
-  float va[MTHA][4];
+  // ---- stage A: s_conv1 on the 5 x 160 tile, by columns of m-tiles (wave, wave + 4 together; wave + 8 for waves 0 and 1) ----
+  float va[COLS][R1][4];
   float amax = 0.f;
   {
-    int aoff[MTHA];
-#pragma unroll
-    for (int i = 0; i < MTHA; ++i) {
-      int t = wave * MTHA + i;
-      t = t < MTA ? t : 0;
-      const int ry = t / MTRA, mt = t - ry * MTRA;
-      aoff[i] = (ry * S1 * PIXA1 + S1 * (16 * mt + lrow)) * C0 + 8 * g;
-    }
-    f32x4 acc[MTHA];
-#pragma unroll
-    for (int i = 0; i < MTHA; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < NKA; ++ks) {
-      const int ky = ks >> 1, kh = ks & 1;
-      const int toff = (ky * PIXA1 + 8 * kh) * C0;
-      if (ks + 2 < NKA) FRONT_LOAD_B1((ks + 2) % 3, ks + 2)
-      const f16x8 bh = bq[ks % 3][0], bl = bq[ks % 3][1];
-      f16x8 fh[MTHA], fl[MTHA];
-#pragma unroll
-      for (int i = 0; i < MTHA; ++i) {
-        fh[i] = *reinterpret_cast<const f16x8*>(sh + aoff[i] + toff);
-        fl[i] = *reinterpret_cast<const f16x8*>(sl + aoff[i] + toff);
-      }
-#pragma unroll
-      for (int i = 0; i < MTHA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bh, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MTHA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], bh, acc[i], 0, 0, 0);
-#pragma unroll
-      for (int i = 0; i < MTHA; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bl, acc[i], 0, 0, 0);
-    }
-    FRONT_LOAD_B2(0, 0)
-    FRONT_LOAD_B2(1, 1)
-    // bias + ReLU; positions outside the s_conv1 image are zero (finite, and out of the tile maximum)
     const float inv = 1.0f / (s_in * a.sw1);
     const float bv = a.b1[lrow];
-#pragma unroll
-    for (int i = 0; i < MTHA; ++i) {
-      const int t = wave * MTHA + i;
-      const int ry = t / MTRA, mt = t - ry * MTRA;
+    // bias + ReLU; positions outside the s_conv1 image are zero (finite, and out of the tile maximum)
+    auto finish = [&](const f32x4& acc, int col, int ry, float (&dst)[4]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int p = 16 * mt + 4 * g + r;
-        const bool ok = t < MTA && oy1 + ry < a.OH1 && x0 + p < a.OW1;
-        const float v = ok ? fmaxf(fmaf(acc[i][r], inv, bv), 0.0f) : 0.0f;
-        va[i][r] = v;
+        const int p = 16 * col + 4 * g + r;
+        const bool ok = oy1 + ry < a.OH1 && x0 + p < a.OW1;
+        const float v = ok ? fmaxf(fmaf(acc[r], inv, bv), 0.0f) : 0.0f;
+        dst[r] = v;
         amax = fmaxf(amax, v);
       }
+    };
+    {
+      f32x4 acc[2][R1];
+      front_stage_a<2>(sh, sl, wave, lrow, g, wh, wl, acc);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int ry = 0; ry < R1; ++ry) finish(acc[c][ry], wave + NWF * c, ry, va[c][ry]);
+    }
+    if (wave + 2 * NWF < MTRA) {   // wave-uniform
+      f32x4 acc[1][R1];
+      front_stage_a<1>(sh, sl, wave + 2 * NWF, lrow, g, wh, wl, acc);
+#pragma unroll
+      for (int ry = 0; ry < R1; ++ry) finish(acc[0][ry], wave + 2 * NWF, ry, va[2][ry]);
+    } else {
+#pragma unroll
+      for (int ry = 0; ry < R1; ++ry)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) va[2][ry][r] = 0.f;
     }
   }
+  // s_conv2's first weight steps travel under the tile exchange below
+  const _Float16* wbase2 = a.wp2 + lane * 8;
+  f16x8 bq[3][2][2];   // [ring slot][n-tile][hi, lo]
+#define FRONT_LOAD_B2(SLOT, KS)                                                                         \
+  {                                                                                                     \
+    const _Float16* q = wbase2 + (size_t)(KS) * (2 * 2 * 512);                                          \
+    bq[SLOT][0][0] = *reinterpret_cast<const f16x8*>(q);                                                \
+    bq[SLOT][0][1] = *reinterpret_cast<const f16x8*>(q + 512);                                          \
+    bq[SLOT][1][0] = *reinterpret_cast<const f16x8*>(q + 1024);                                         \
+    bq[SLOT][1][1] = *reinterpret_cast<const f16x8*>(q + 1536);                                         \
+  }
+  FRONT_LOAD_B2(0, 0)
+  FRONT_LOAD_B2(1, 1)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_down(amax, off, 64));
   if (lane == 0) wg_red[8 + wave] = amax;
   __syncthreads();   // every wave has finished reading the input strip
   amax = wg_red[8];
 #pragma unroll
-  for (int w = 1; w < 8; ++w) amax = fmaxf(amax, wg_red[8 + w]);
+  for (int w = 1; w < NWF; ++w) amax = fmaxf(amax, wg_red[8 + w]);
   const float s_mid = ovn_pow2_scale_for(amax);
   // intermediate tile -> LDS as [row][pixel][16 channels] hi / lo: lane = channel lrow of pixels 4 g .. 4 g + 3 of each m-tile
 #pragma unroll
-  for (int i = 0; i < MTHA; ++i) {
-    const int t = wave * MTHA + i;
-    if (t < MTA) {
-      const int ry = t / MTRA, mt = t - ry * MTRA;
+  for (int c = 0; c < COLS; ++c) {
+    const int col = wave + NWF * c;
+    if (col < MTRA && (!(FRONT_ABL & 32) || amax == 123.456f)) {
 #pragma unroll
-      for (int r = 0; r < 4; r += 2) {
-        _Float16 h0, h1, l0, l1;
-        const float x0f = va[i][r] * s_mid, x1f = va[i][r + 1] * s_mid;
-        const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0f, x1f));
-        h0 = hp[0];
-        h1 = hp[1];
-        l0 = (_Float16)__builtin_fmaf(x0f, one, -(float)hp[0]);
-        l1 = (_Float16)__builtin_fmaf(x1f, one, -(float)hp[1]);
-        const int o = (ry * PIXM + 16 * mt + 4 * g + r) * C1 + lrow;
-        mh[o] = h0;
-        mh[o + C1] = h1;
-        ml[o] = l0;
-        ml[o + C1] = l1;
+      for (int ry = 0; ry < R1; ++ry) {
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const float x0f = va[c][ry][r] * s_mid, x1f = va[c][ry][r + 1] * s_mid;
+          const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0f, x1f));
+          const _Float16 l0 = (_Float16)__builtin_fmaf(x0f, one, -(float)hp[0]);
+          const _Float16 l1 = (_Float16)__builtin_fmaf(x1f, one, -(float)hp[1]);
+          const int o = (ry * PIXM + 16 * col + 4 * g + r) * C1 + lrow;
+          mh[o] = hp[0];
+          mh[o + C1] = hp[1];
+          ml[o] = l0;
+          ml[o + C1] = l1;
+        }
       }
     }
   }
   __syncthreads();   // tile complete
 
-  // ---- stage B: s_conv2 on the tile.  waves = 2 n-tiles x 4 rows of m-tiles; m-tile t = 5 wm + i: row t / 9, pixels 16 (t % 9) .. ----
+  // ---- stage B: s_conv2 on the tile.  m-tile t = wave + 4 i: row t / 9, pixels 16 (t % 9) ..; both n-tiles ----
   {
-    const int wn = wave & 1, wm = wave >> 1;
     int aoff[MTHB];
 #pragma unroll
     for (int i = 0; i < MTHB; ++i) {
-      int t = wm * MTHB + i;
+      int t = wave + NWF * i;
       t = t < MTB ? t : 0;
       const int ry = t / MTRB, mt = t - ry * MTRB;
       aoff[i] = (ry * SH2 * PIXM + 16 * mt + lrow) * C1 + 8 * g;
     }
-    f32x4 acc[MTHB];
+    const bool last = wave + NWF * (MTHB - 1) < MTB;   // wave-uniform: does slot MTHB - 1 hold a tile?
+    f32x4 acc[MTHB][2];
 #pragma unroll
-    for (int i = 0; i < MTHB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MTHB; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < NKB; ++ks) {
+    for (int ks = 0; ks < ((FRONT_ABL & 4) ? 1 : NKB); ++ks) {
       const int ky = ks >> 3, kh = ks & 7;
       const int toff = (ky * PIXM + 2 * kh) * C1;
       if (ks + 2 < NKB) FRONT_LOAD_B2((ks + 2) % 3, ks + 2)
-      const f16x8 bh = bq[ks % 3][0], bl = bq[ks % 3][1];
       f16x8 fh[MTHB], fl[MTHB];
 #pragma unroll
       for (int i = 0; i < MTHB; ++i) {
@@ -253,37 +308,45 @@ __global__ __launch_bounds__(512, 4) void leg_front_kernel(FrontArgs a) {   // 4
         fl[i] = *reinterpret_cast<const f16x8*>(ml + aoff[i] + toff);
       }
 #pragma unroll
-      for (int i = 0; i < MTHB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bh, acc[i], 0, 0, 0);
+      for (int j = 0; j < 2; ++j) {
 #pragma unroll
-      for (int i = 0; i < MTHB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[i], bh, acc[i], 0, 0, 0);
+        for (int i = 0; i < MTHB; ++i)
+          if (i + 1 < MTHB || last) acc[i][j] = FRONT_MFMA(fh[i], bq[ks % 3][j][0], acc[i][j]);
 #pragma unroll
-      for (int i = 0; i < MTHB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[i], bl, acc[i], 0, 0, 0);
+        for (int i = 0; i < MTHB; ++i)
+          if (i + 1 < MTHB || last) acc[i][j] = FRONT_MFMA(fl[i], bq[ks % 3][j][0], acc[i][j]);
+#pragma unroll
+        for (int i = 0; i < MTHB; ++i)
+          if (i + 1 < MTHB || last) acc[i][j] = FRONT_MFMA(fh[i], bq[ks % 3][j][1], acc[i][j]);
+      }
     }
     const float inv = 1.0f / (s_mid * a.sw2);
-    const int n = 16 * wn + lrow;
-    const float bv = a.b2[n];
     float vmax = 0.f;
 #pragma unroll
-    for (int i = 0; i < MTHB; ++i) {
-      const int t = wm * MTHB + i;
-      const int ry = t / MTRB, mt = t - ry * MTRB;
-      float* orow = a.out + (((long long)b * a.OH2 + oy2 + ry) * a.OW2 + x0) * C2;
+    for (int j = 0; j < 2; ++j) {
+      const int n = 16 * j + lrow;
+      const float bv = a.b2[n];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int p = 16 * mt + 4 * g + r;
-        if (p < tw && t < MTB && oy2 + ry < a.OH2) {
-          const float v = fmaxf(fmaf(acc[i][r], inv, bv), 0.0f);
-          orow[(long long)p * C2 + n] = v;
-          vmax = fmaxf(vmax, v);
+      for (int i = 0; i < MTHB; ++i) {
+        const int t = wave + NWF * i;
+        const int ry = t / MTRB, mt = t - ry * MTRB;
+        float* orow = a.out + (((long long)b * a.OH2 + oy2 + ry) * a.OW2 + x0) * C2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * mt + 4 * g + r;
+          if (p < tw && t < MTB && oy2 + ry < a.OH2) {
+            const float v = fmaxf(fmaf(acc[i][j][r], inv, bv), 0.0f);
+            if (!(FRONT_ABL & 8) || v == 123.456f) orow[(long long)p * C2 + n] = v;
+            vmax = fmaxf(vmax, v);
+          }
         }
       }
     }
     if (a.out_max) ovn_fold_absmax_wg(vmax, a.out_max + (size_t)b * OVN_ACTMAX_STRIDE, wg_red);   // kernel-uniform condition
   }
 }
-
-#undef FRONT_LOAD_B1
 #undef FRONT_LOAD_B2
+#undef FRONT_MFMA
 
 bool is_layer(const OvnConvLayer& L, int kh, int kw, int cin, int cout, int sh, int sw) {
   return L.relu && L.kh == kh && L.kw == kw && L.cin == cin && L.cout == cout && L.sh == sh && L.sw == sw && L.wp_h16 != nullptr;
@@ -327,7 +390,7 @@ int ovn_leg_front_forward(const ovn_ctx* ctx, size_t first, const float* in, int
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(leg_front_kernel), FRONT_LDS);
   if (rc) return rc;
   const long long wgs = (long long)nb * ((a.OH2 + RB - 1) / RB) * a.XT;
-  hipLaunchKernelGGL(leg_front_kernel, dim3((unsigned)wgs), dim3(512), FRONT_LDS, stream, a);
+  hipLaunchKernelGGL(leg_front_kernel, dim3((unsigned)wgs), dim3(NTHR), FRONT_LDS, stream, a);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
