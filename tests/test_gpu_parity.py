@@ -140,14 +140,14 @@ def test_leg_f16x3_mode(engines, fixture_images, C):
 
 
 def test_leg_batch_tail_and_slicing(engines, fixture_images):
-    """n not a multiple of any tile, and > the internal 256-scan slice: same result per scan."""
+    """n not a multiple of any tile, and > the internal 1024-scan slice (1027 scans = slices of 514 + 513): same result per scan."""
     imgs = fixture_images(4)
     e = engines[4]
     one = e.leg(torch.from_numpy(imgs[:1]).cuda())
     assert torch.equal(one, e.leg(torch.from_numpy(imgs[:1]).cuda()))      # run-to-run deterministic
-    many = torch.from_numpy(np.repeat(imgs[:1], 259, axis=0)).cuda()
+    many = torch.from_numpy(imgs[:1]).cuda().expand(1027, -1, -1, -1).contiguous()
     out = e.leg(many)
-    assert torch.equal(out, out[:1].expand(259, -1, -1))                     # every batch position identical
+    assert torch.equal(out, out[:1].expand(1027, -1, -1))                    # every batch position identical
     assert torch.equal(one, out[:1])                                         # ... and identical to the scan computed alone
     e.set_leg_precision("f32")
     try:
@@ -161,7 +161,7 @@ def test_leg_batch_tail_and_slicing(engines, fixture_images):
 def test_leg_result_does_not_depend_on_the_batch(engines, fixture_images, C):
     """A scan's feature volume depends on that scan alone (reference: `leg.predict_generator`, infer.py:262-265): computed alone, in a
     batch of 9 next to a 300x-scaled neighbour (which moves every call-wide activation maximum by 8 powers of two), at another
-    position, and in a batch of 259 that crosses the 256-scan slice -- the same bits, in the default (f16x3) arithmetic."""
+    position, and in a batch of 1027 that is cut into two slices (514 + 513 scans) -- the same bits, in the default (f16x3) arithmetic."""
     imgs = fixture_images(C)
     e = engines[C]
     a = torch.from_numpy(imgs[:1]).cuda()
@@ -174,9 +174,10 @@ def test_leg_result_does_not_depend_on_the_batch(engines, fixture_images, C):
     assert torch.equal(out9[1:2], alone) and torch.equal(out9[7:8], alone)
     assert torch.equal(out9[2], out9[5]) and torch.equal(out9[0], out9[4]) and torch.equal(out9[3], out9[8])
     assert torch.equal(out9[2:3], e.leg(b))
-    big = torch.cat([b.expand(257, -1, -1, -1), a, loud]).contiguous()          # scan `a` sits in the second slice
+    big = torch.cat([b.expand(513, -1, -1, -1), a, loud, b.expand(511, -1, -1, -1), a]).contiguous()   # `a`: last of slice 1, last of slice 2
     outb = e.leg(big)
-    assert outb.shape[0] == 259 and torch.equal(outb[257:258], alone) and torch.equal(outb[258:259], out9[0:1])
+    assert outb.shape[0] == 1027 and torch.equal(outb[513:514], alone) and torch.equal(outb[1026:1027], alone)
+    assert torch.equal(outb[514:515], out9[0:1]) and torch.equal(outb[0:1], out9[2:3]) and torch.equal(outb[700:701], out9[2:3])
     # the scaled scans are still computed to fp32-equivalent accuracy relative to their own range (their own scales apply)
     ref = e.leg(b)
     assert torch.equal(e.leg(loud), out9[0:1])

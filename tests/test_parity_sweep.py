@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CFG = S.REFERENCE_MODEL_CFG
 # (weight set, channels, pool): the benchmark configuration with both weight sets, and a shorter sweep at the other two channel
 # counts the reference's configs produce (depth only; depth + normals + intensity) with the wide-range weights
-# the 4096-candidate pool crosses the 2048-pair chunk boundary of the heads and the 256-scan slices of the leg
+# the 4096-candidate pool crosses the 2048-pair chunk boundary of the heads and the 1024-scan slices of the leg
 CASES = [("glorot", 4, 1024), ("trained_like", 4, 1024), ("trained_like", 1, 128), ("trained_like", 5, 128), ("trained_like", 4, 4096)]
 
 # (name, leg arithmetic, head arithmetic, correlation form); the first row is what bench.py and `Infer` run by default
