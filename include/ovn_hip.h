@@ -82,9 +82,10 @@ int ovn_finalize(ovn_ctx* ctx, int* feat_w);
 /* Leg: images_dev (n, in_h, in_w, in_c) -> features_dev (n, feat_w, 128).
  * Replaces `leg.predict_generator` in Infer.create_feature_volumes (infer.py:262-265).
  * A scan's feature volume depends on that scan alone: every call size runs the same kernels, and the power-of-two scales of the
- * f16x3 arithmetic are taken per scan (per strip / tile inside the first layer and the fused tail) -- the same scan computed alone,
+ * f16x3 arithmetic are taken per scan (per strip / tile inside the fused first two layers and the fused tail) -- the same scan computed alone,
  * inside any batch, at any position and next to any other scans gives the same bits (the reference's `predict_generator` results
- * do not depend on batch composition either, infer.py:262-265). */
+ * do not depend on batch composition either, infer.py:262-265).  Calls of more than 1024 scans are processed in equal slices of at
+ * most 1024 (scratch: 2 x slice x 770 KB at in_c = 4, i.e. up to 1.6 GB, see ovn_workspace_bytes). */
 int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_dev, void* stream);
 
 /* Both heads on n pairs.  Pair p uses l = feats_l_dev[lidx[p]] and r = feats_r_dev[ridx[p]]

@@ -285,10 +285,11 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
     const float* cur = images_dev + (size_t)s0 * in_elems;
     int h = ctx->in_h, w = ctx->in_w;
     if (ctx->leg_mode != 0) {
-      // f16x3: word [li][scan] = max |input of layer li| of that scan, folded by the kernel that produces it.  Scales are per scan
+      // f16x3: word [li][scan of the slice] (rows of `slice` words: a one-scan call clears 12 words, not 12 x 1024) = max |input of
+      // layer li| of that scan, folded by the kernel that produces it.  Scales are per scan
       // and every call size runs the same kernels, so a scan's feature volume does not depend on the batch it is computed in
       // (the first layer's kernel at C = 4 and the fused tail take the maximum of their own strip / tile instead)
-      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, (ctx->leg.size() + 1) * OVN_LEG_SLICE * OVN_ACTMAX_STRIDE * sizeof(unsigned), stream));
+      OVN_HIP_CHECK(hipMemsetAsync(ctx->actmax, 0, (ctx->leg.size() + 1) * (size_t)slice * OVN_ACTMAX_STRIDE * sizeof(unsigned), stream));
       const bool own = (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_conv_strip_own_scale(ctx->leg[0], n, h, w);
       if (!own) {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
@@ -305,7 +306,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       if (ctx->leg_mode != 0 && li == 0 && !no_front && (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_leg_front_matches(ctx, li, h, w)) {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         float* dst2 = buf[(li + 1) & 1];
-        rc = ovn_leg_front_forward(ctx, li, cur, nb, h, w, dst2, &oh, &ow, ctx->actmax + (li + 2) * (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE, stream);
+        rc = ovn_leg_front_forward(ctx, li, cur, nb, h, w, dst2, &oh, &ow, ctx->actmax + (li + 2) * (size_t)slice * OVN_ACTMAX_STRIDE, stream);
         if (rc) return rc;
         cur = dst2;
         h = oh;
@@ -323,8 +324,8 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         rc = (ctx->leg_mode == 0) ? ovn_conv_forward(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, stream)
-                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li * (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE,
-                                                           last ? nullptr : ctx->actmax + (li + 1) * (size_t)OVN_LEG_SLICE * OVN_ACTMAX_STRIDE, stream);
+                                  : ovn_conv_forward_f16x3(ctx->leg[li], cur, nb, h, w, dst, &oh, &ow, ctx->actmax + li * (size_t)slice * OVN_ACTMAX_STRIDE,
+                                                           last ? nullptr : ctx->actmax + (li + 1) * (size_t)slice * OVN_ACTMAX_STRIDE, stream);
       }
       if (rc) return rc;
       cur = dst;
