@@ -302,8 +302,7 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
       float* dst = last ? features_dev + (size_t)s0 * OVN_FEAT_ELEMS : buf[li & 1];
       int oh = 0, ow = 0;
       // f16x3, C = 4: s_conv1 + s_conv2 as one kernel (the activation between them never leaves the CU)
-      static const bool no_front = getenv("OVN_NO_LEG_FRONT") != nullptr;   // A/B switch for tools/experiments
-      if (ctx->leg_mode != 0 && li == 0 && !no_front && (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_leg_front_matches(ctx, li, h, w)) {
+      if (ctx->leg_mode != 0 && li == 0 && (reinterpret_cast<uintptr_t>(cur) & 15) == 0 && ovn_leg_front_matches(ctx, li, h, w)) {
         OvnProfScope ps(ctx, OVN_K_LEG, stream);
         float* dst2 = buf[(li + 1) & 1];
         rc = ovn_leg_front_forward(ctx, li, cur, nb, h, w, dst2, &oh, &ow, ctx->actmax + (li + 2) * (size_t)slice * OVN_ACTMAX_STRIDE, stream);
