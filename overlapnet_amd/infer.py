@@ -259,30 +259,25 @@ class Infer():
           return
     dst[...] = np.load(path)
 
-  def _inputs_device(self, filenames: Sequence[str]) -> torch.Tensor:
-    """(n,h,w,C) leg input on the device: every cue's files are read straight into a pinned staging buffer (depth (n,h,w),
-    normals (n,h,w,3), ...), copied asynchronously and interleaved by one device-side concatenation (a strided host-side
-    interleave plus a pageable copy cost more than the leg itself for a single frame)."""
+  def _ensure_stage(self, n: int) -> None:
+    """Two sets of pinned staging buffers used alternately: a set is free again once ITS host-to-device copies are done (an event
+    recorded right behind them), not when the leg that consumes the device copy has finished -- the host never waits for the GPU."""
     h, w, c = self.inputShape
-    n = len(filenames)
-    root = os.path.join(self.datasetpath, self.seq)
-    dev = self.engine.device
-    # two sets of pinned staging buffers used alternately: a set is free again once ITS host-to-device copies are done (an event
-    # recorded right behind them), not when the leg that consumes the device copy has finished -- the host never waits for the GPU
     if getattr(self, '_stage', None) is None or self._stage_n < n:
       self._stage_n = max(n, 1)
       self._stage = [{sub: torch.empty((self._stage_n, h, w) + ((k,) if k > 1 else ()), dtype=torch.float32).pin_memory()
                       for sub, k, _ in self._cue_files()} for _ in range(2)]
       self._stage_free = [None, None]
       self._stage_next = 0
-    slot = self._stage_next
-    self._stage_next ^= 1
+      self._ahead = None
+
+  def _read_cues(self, slot: int, filenames: Sequence[str]) -> None:
+    """Every cue's files of `filenames` straight into staging set `slot` (depth (n,h,w), normals (n,h,w,3), ...)."""
+    root = os.path.join(self.datasetpath, self.seq)
     if self._stage_free[slot] is not None:
       self._stage_free[slot].synchronize()
-    parts = []
     for sub, k, label in self._cue_files():
-      host = self._stage[slot][sub][:n]
-      hv = host.numpy()
+      hv = self._stage[slot][sub][:len(filenames)].numpy()
       for i, name in enumerate(filenames):
         f = os.path.join(root, sub, name + '.npy')
         try:
@@ -291,7 +286,36 @@ class Infer():
           if label is not None:
             raise Exception('Could not read %s image %s' % (label, f))
           hv[i] = np.load(os.path.join(root, sub, name + '.npz'))
-      d = host.to(dev, non_blocking=True)
+
+  def _readahead(self, filenames: Sequence[str]) -> None:
+    """Read the files the NEXT call will most likely ask for into the staging set that call will use, while the GPU is busy with the
+    current one (a streaming loop-closure run asks for frame i + 1 after frame i; the reads of one frame cost ~0.15 ms of host time
+    that would otherwise sit between two frames with the GPU idle).  Purely speculative: any failure, or a different request, and
+    the next call reads its files as usual."""
+    try:
+      self._ensure_stage(len(filenames))
+      slot = self._stage_next
+      self._ahead = None
+      self._read_cues(slot, filenames)
+      self._ahead = (tuple(filenames), slot)
+    except Exception:
+      self._ahead = None
+
+  def _inputs_device(self, filenames: Sequence[str]) -> torch.Tensor:
+    """(n,h,w,C) leg input on the device: every cue's files are read straight into a pinned staging buffer, copied asynchronously
+    and interleaved by one device-side concatenation (a strided host-side interleave plus a pageable copy cost more than the leg
+    itself for a single frame)."""
+    n = len(filenames)
+    dev = self.engine.device
+    self._ensure_stage(n)
+    slot = self._stage_next
+    self._stage_next ^= 1
+    if self._ahead != (tuple(filenames), slot):
+      self._read_cues(slot, filenames)
+    self._ahead = None
+    parts = []
+    for sub, k, label in self._cue_files():
+      d = self._stage[slot][sub][:n].to(dev, non_blocking=True)
       parts.append(d if k > 1 else d.unsqueeze(-1))
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
@@ -336,8 +360,10 @@ class Infer():
                                dcache_l=cache.device_delta_cache)
     return self.engine.heads(feats, feats, lidx=left, ridx=right, n=len(right), spec_l=spec, spec_r=spec)
 
-  def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray):
+  def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray, ahead: Optional[Sequence[str]] = None):
     r = self._heads_device(cache, pair_indizes)
+    if ahead:
+      self._readahead(ahead)      # host file reads in the shadow of the head kernels just enqueued
     res = torch.stack([r["overlap"].view(torch.int32), r["yaw"]]).cpu().numpy()      # ONE device-to-host copy for both
     overlap = res[0].view(np.float32).reshape(-1, 1)
     yaw = res[1].astype(np.int64)
@@ -377,7 +403,11 @@ class Infer():
       n = len(self.feature_volumes)
       if pair_indizes.min() < 0 or pair_indizes.max() >= n:
         raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(pair_indizes.max()), n))
-      overlap, yaw = self._run_heads(self.feature_volumes, pair_indizes)
+      try:
+        ahead = [str(int(current_frame_id) + 1).zfill(6)]    # a streaming run asks for the next frame next
+      except (TypeError, ValueError):
+        ahead = None
+      overlap, yaw = self._run_heads(self.feature_volumes, pair_indizes, ahead)
       return overlap.squeeze(), yaw
     else:
       return None
@@ -400,7 +430,9 @@ class Infer():
     pair_indizes[:, 1] = int(current_frame_id)
     r = self._heads_device(self.feature_volumes, pair_indizes)
     ids = torch.from_numpy(ref.astype(np.int32)).to(self.engine.device)
-    return decode_match(self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=ids))
+    rec = self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=ids)
+    self._readahead([str(int(current_frame_id) + 1).zfill(6)])    # next frame's files, in the shadow of the kernels just enqueued
+    return decode_match(rec)
 
   def infer_multiple_vs_multiple(self, file_names, first_idxs, second_idxs):
     """ Multiple pairs (infer.py:205-238): pair i = (file_names[first_idxs[i]], file_names[second_idxs[i]]);

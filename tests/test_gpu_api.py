@@ -175,3 +175,39 @@ def test_c_abi_collective_one_rank():
     _lib.check(lib.ovn_comm_destroy(h), "ovn_comm_destroy")
     assert lib.ovn_gather_scores(h, ov.data_ptr(), yw.data_ptr(), counts, 0, ov_all.data_ptr(), yw_all.data_ptr(), stream) != 0
     eng.close()
+
+
+def test_streaming_readahead_changes_nothing(tmp_path, fixture_npz):
+    """`infer_multiple(i, ...)` reads frame i + 1's files ahead, in the shadow of its head kernels (host plumbing of the demo3 loop,
+    demo3_lcd.py:88-123).  A run that hits the read-ahead, one that asks for other frames than the guessed ones, and one with the
+    read-ahead disabled must return the same bits; a guess that names a missing file must not surface as an error."""
+    from overlapnet_amd.infer import Infer
+    root = tmp_path / "data"
+    _write_sequence(str(root), fixture_npz, 6)
+    w = S.make_test_weights(4, seed=0)
+
+    def run(readahead):
+        inf = Infer(_config(root), weights=w)
+        if not readahead:
+            inf._readahead = lambda names: None
+        out, hits = [], 0
+        for i in range(6):
+            guess = getattr(inf, "_ahead", None)
+            hits += int(guess is not None and guess[0] == ("%06d" % i,))
+            out.append(inf.infer_multiple(i, list(range(i))))
+        return out, hits
+
+    a, hits_a = run(True)      # frames 2 .. 5 come out of the read-ahead (frame 0's call has no heads to hide behind; frame 6 does
+    b, hits_b = run(False)     # not exist: that guess fails silently)
+    assert hits_a == 4 and hits_b == 0
+    for i in range(1, 6):
+        assert np.array_equal(a[i][0], b[i][0]) and np.array_equal(a[i][1], b[i][1])
+    # a guess that is wrong: frame 1's call reads frame 2 ahead, but frame 4's files are then asked for through create_feature_volumes
+    inf = Infer(_config(root), weights=w)
+    inf.infer_multiple(0, [])
+    inf.infer_multiple(1, [0])
+    assert inf._ahead is not None and inf._ahead[0] == ("000002",)
+    fv4 = inf.create_feature_volumes(["000004"])
+    ref = Infer(_config(root), weights=w)
+    ref._readahead = lambda names: None
+    assert np.array_equal(fv4, ref.create_feature_volumes(["000004"])) and inf._ahead is None
