@@ -10,8 +10,10 @@ heads of that query against the candidate feature volumes cached in HBM ("warm" 
 when they were the current frame, infer.py:184-185).
 
 N = 1 (default): P = 1024 candidates, C = 4 = BASELINE.json configs[1] ("batched 1-vs-1024 pairs, 64x900 depth+normals").
-`value` is that warm sweep.  The same run then measures, each in its own timed region and reported as sub-records of the
-ONE JSON line: `fp32_mode` (every contraction on the fp32 matrix cores), `cold` (candidate legs inside the step),
+`value` is that warm sweep for a STREAM of queries: every step enqueues one query leg and one 1024-pair head sweep, the leg (and
+spectrum) of query k + 1 on a second context / stream beside the head kernels of query k (overlapnet_amd.engine.QueryAhead;
+`--serial-query` puts the leg in front of its own heads on one stream instead).  The same run then measures, each in its own
+timed region and reported as sub-records of the ONE JSON line: `warm_serial` (that one-stream order), `fp32_mode` (every contraction on the fp32 matrix cores), `cold` (candidate legs inside the step),
 `fullstack` (raw clouds -> projection -> legs -> heads), `corr_head` (the HBM-bound correlation head alone at N = 1024 and
 16384), `infer_api` (BASELINE configs[2]: the 1101-frame loop-closure sweep through `Infer.infer_multiple`), `latency` (one query
 against N = 1 [configs[0]], 16, 100, 256 candidates), and the accuracy of the timed configuration over ALL pairs against the
@@ -142,9 +144,10 @@ def relaunch_env(env):
     return e
 
 
-def timed(step, warmup, steps, eng, use_dist, dev):
+def timed(step, warmup, steps, eng, use_dist, dev, side_eng=None):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides; max over ranks.
-    Returns (elapsed_s, per-kernel HIP-event profile, last step result)."""
+    Returns (elapsed_s, per-kernel HIP-event profile, last step result).  `side_eng`: a second library context whose kernels
+    (the query leg of QueryAhead) belong to the same steps; its event times are merged into the profile."""
     res = None
     for _ in range(warmup):
         res = step()
@@ -152,6 +155,8 @@ def timed(step, warmup, steps, eng, use_dist, dev):
     if use_dist:
         dist.barrier()
     eng.profile_begin()
+    if side_eng is not None:
+        side_eng.profile_begin()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -162,6 +167,9 @@ def timed(step, warmup, steps, eng, use_dist, dev):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     prof = eng.profile_end()
+    if side_eng is not None:
+        for k, (ms, cnt) in side_eng.profile_end().items():
+            prof[k] = (prof[k][0] + ms, prof[k][1] + cnt)
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -212,6 +220,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (path check)")
     ap.add_argument("--no-delta-cache", action="store_true", help="warm sweep without the candidates' Delta cache rows (round-2 behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-query", action="store_true", help="warm mode: the query leg on the heads' stream, in front of them (no QueryAhead)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32_mode / cold / fullstack / corr_head sub-records")
     ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against a LIVE fp64 oracle when no committed "
                                                                   "oracle outputs exist for the configuration (untimed)")
@@ -332,12 +341,30 @@ def main():
             return D.gather_scores(r["overlap"], r["yaw"], n_total)
         return r["overlap"], r["yaw"]
 
-    def step_warm():
+    def step_warm_serial():
         eng.leg(query_img, out=query_fv)
         if spectral:
             eng.spectrum(query_fv, out=query_spec)
             return finish(eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec, dcache_l=cand_dc))
         return finish(eng.heads(cands, query_fv))
+
+    # Streaming queries (the demo3 loop over a recorded sequence): the leg + spectrum of query k + 1 run on a second context and
+    # stream beside the head kernels of query k (overlapnet_amd.engine.QueryAhead).  Every step still enqueues ONE query leg and
+    # ONE 1024-pair head sweep; the pipeline is primed before the warm-up steps, so the K timed steps hold K legs and K sweeps.
+    qa = None
+    if args.mode == "warm" and not args.serial_query:
+        from overlapnet_amd.engine import QueryAhead
+        qa = QueryAhead(eng, w, S.REFERENCE_MODEL_CFG)
+        qa.submit(query_img)
+
+    def step_warm():
+        if qa is None:
+            return step_warm_serial()
+        qa.submit(query_img)
+        fv, sp = qa.take()
+        if spectral:
+            return finish(eng.heads(cands, fv, spec_l=cand_spec, spec_r=sp, dcache_l=cand_dc))
+        return finish(eng.heads(cands, fv))
 
     def make_step_cold(raw):
         def step_cold():
@@ -361,12 +388,14 @@ def main():
         step = make_step_cold(raw)
     else:
         step = step_warm
-    elapsed, prof, res = timed(step, args.warmup, args.steps, eng, use_dist, dev)
+    elapsed, prof, res = timed(step, args.warmup, args.steps, eng, use_dist, dev, side_eng=qa.side if qa is not None else None)
 
     if rank != 0:
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
+        if qa is not None:
+            qa.close()
         eng.close()
         return
 
@@ -399,6 +428,9 @@ def main():
         "config": {"workload": workload, "mode": args.mode, "pairs_per_step": n_total, "pairs_per_rank": P, "channels": C,
                    "weights": "seeded synthetic (no trained weights ship)", "head_precision": args.head_precision,
                    "leg_precision": leg_precision, "correlation_head": args.corr,
+                   "query_leg": ("step k + 1's query leg + spectrum on a second context / stream beside step k's head kernels "
+                                 "(engine.QueryAhead; one leg and one head sweep enqueued per step)" if qa is not None
+                                 else "on the heads' stream, in front of them"),
                    "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": rocprof_traffic(kprefix),
@@ -447,6 +479,12 @@ def main():
     # ---- sub-records: every other number DESIGN.md quotes, measured in this same run (N = 1 only) ----
     if world == 1 and not strong and not args.no_extras and args.mode == "warm":
         sub_steps = max(args.steps, 20)
+        # (0) the same warm step with the query leg IN FRONT of its heads on one stream (no QueryAhead)
+        if qa is not None:
+            e0, p0, r0 = timed(step_warm_serial, 2, sub_steps, eng, False, dev)
+            out["warm_serial"] = {"value": P * sub_steps / e0, "unit": "pairs/s", "ms_per_step": 1e3 * e0 / sub_steps, "steps": sub_steps,
+                                  "step": "1 query leg, then %d head pairs, one stream" % P,
+                                  "same_results": bool(torch.equal(r0[0], res[0]) and torch.equal(r0[1], res[1]))}
         # (1) everything on the fp32 matrix cores, direct correlation form
         eng.set_head_precision("f32")
         eng.set_leg_precision("f32")
@@ -550,6 +588,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if qa is not None:
+        qa.close()
     eng.close()
 
 

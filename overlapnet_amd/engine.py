@@ -447,6 +447,76 @@ class OvnEngine:
         return int(self.lib.ovn_workspace_bytes(self._h))
 
 
+class QueryAhead:
+    """Leg + spectrum of the NEXT query scan on a second library context and HIP stream, beside the head kernels that the caller's
+    stream is running for the CURRENT query (a recorded sequence, or a live one whose next scan has arrived: the 1-vs-N sweep of
+    `Infer.infer_multiple`, infer.py:162-203, spends 0.15 ms of its ~5.6 ms per query in a single-scan leg whose five kernels are a
+    handful of workgroups deep in their own latency and leave the GPU idle).  A context owns its scratch, hence the second context;
+    features and spectra are double-buffered, so a result stays valid until the submit after the next.
+
+        qa = QueryAhead(engine, weights, model_cfg)
+        qa.submit(image_0)
+        for k in range(n):
+            if k + 1 < n: qa.submit(image_{k+1})          # enqueued on the side stream, returns at once
+            fv, spec = qa.take()                          # the current stream now waits for query k's features (not the host)
+            engine.heads(cands, fv, spec_l=cand_spec, spec_r=spec, dcache_l=cand_dc)
+
+    Same kernels, same bits as `engine.leg` / `engine.spectrum` on the caller's stream (tests/test_gpu_parity.py)."""
+
+    def __init__(self, engine: OvnEngine, weights: Dict[str, np.ndarray], model_cfg: Optional[dict] = None):
+        self.main = engine
+        self.side = OvnEngine(engine.in_h, engine.in_w, engine.in_c, device=engine.device_index)
+        self.side.load_weights(weights, model_cfg)
+        self.side.set_leg_precision(engine.leg_precision)
+        self.side.set_head_precision(engine.head_precision)       # the spectrum kernel follows the head arithmetic
+        dev = engine.device
+        with torch.cuda.device(dev):
+            self.stream = torch.cuda.Stream(device=dev)
+            self._fv = [torch.empty((1, FEAT_W, FEAT_C), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._spec = [torch.empty((1, FEAT_C, engine.SPEC_W), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self._released = [None, None]      # recorded on the consumer's stream when a slot's results are handed out again
+        self._submitted = 0
+        self._taken = 0
+
+    def submit(self, image: torch.Tensor, wait_current: bool = True) -> None:
+        """Enqueue leg + spectrum of `image` (1, in_h, in_w, in_c) on the side stream; at most two queries may be in flight.
+        `wait_current=False`: the image was produced on `self.stream` itself (e.g. its host-to-device copy was issued there), so the
+        side stream need not wait for the work already enqueued on the caller's stream."""
+        if self._submitted - self._taken >= 2:
+            raise _lib.OvnError("QueryAhead.submit: two queries are already in flight, take() one first")
+        slot = self._submitted & 1
+        if wait_current:
+            self.stream.wait_stream(torch.cuda.current_stream(self.main.device))   # the image belongs to the caller's stream
+        if self._released[slot] is not None:
+            self.stream.wait_event(self._released[slot])     # the heads that read this slot two queries ago are done with it
+        with torch.cuda.stream(self.stream):
+            self.side.leg(image, out=self._fv[slot])
+            self.side.spectrum(self._fv[slot], out=self._spec[slot])
+            self._ready[slot].record(self.stream)
+        image.record_stream(self.stream)
+        self._submitted += 1
+
+    def take(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(feature volume (1, 360, 128), spectrum) of the oldest submitted query; the CURRENT stream waits for them, the host does
+        not.  The pair stays valid until the second submit() after this call."""
+        if self._taken >= self._submitted:
+            raise _lib.OvnError("QueryAhead.take: nothing submitted")
+        slot = self._taken & 1
+        cur = torch.cuda.current_stream(self.main.device)
+        cur.wait_event(self._ready[slot])
+        other = slot ^ 1
+        ev = torch.cuda.Event()          # work enqueued on `cur` so far includes every reader of the OTHER slot's previous contents
+        ev.record(cur)
+        self._released[other] = ev
+        self._taken += 1
+        return self._fv[slot], self._spec[slot]
+
+    def close(self) -> None:
+        self.stream.synchronize()
+        self.side.close()
+
+
 def decode_match(record) -> Optional[Tuple[int, float, int]]:
     """(candidate id, overlap, yaw) from a best-match record, or None when nothing exceeded the threshold."""
     import numpy as np

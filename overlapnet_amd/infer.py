@@ -205,6 +205,9 @@ class Infer():
       print('Pre-trained weights was not found in:', pretrained_weightsfilename)
       w = W.keras_default_init(self.no_input_channels, self._model_cfg, seed)
     self.engine.load_weights(w, self._model_cfg)
+    self._weights = w           # kept for the second context of the streaming path (_start_ahead)
+    self._qa = None
+    self._ahead_fv = None       # name of the frame whose leg is running (or done) on the side stream
 
   @property
   def feature_volumes(self):
@@ -360,10 +363,10 @@ class Infer():
                                dcache_l=cache.device_delta_cache)
     return self.engine.heads(feats, feats, lidx=left, ridx=right, n=len(right), spec_l=spec, spec_r=spec)
 
-  def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray, ahead: Optional[Sequence[str]] = None):
+  def _run_heads(self, cache: FeatureVolumeCache, pair_indizes: np.ndarray, ahead=None):
     r = self._heads_device(cache, pair_indizes)
-    if ahead:
-      self._readahead(ahead)      # host file reads in the shadow of the head kernels just enqueued
+    if ahead is not None:
+      self._start_ahead(ahead)    # next frame: file reads, copy and leg in the shadow of the head kernels just enqueued
     res = torch.stack([r["overlap"].view(torch.int32), r["yaw"]]).cpu().numpy()      # ONE device-to-host copy for both
     overlap = res[0].view(np.float32).reshape(-1, 1)
     yaw = res[1].astype(np.int64)
@@ -390,11 +393,50 @@ class Infer():
     overlap, yaw = self._run_heads(pair, indizes)
     return overlap[0], yaw
 
+  # ---- streaming: the NEXT frame's files, host-to-device copy and leg in the shadow of the CURRENT frame's head kernels ----------
+  def _start_ahead(self, current_frame_id) -> None:
+    """After the head kernels of frame i have been enqueued: read frame i + 1's cue files (host, ~0.15 ms), then copy them and run
+    their leg on a second library context and stream (engine.QueryAhead) beside those head kernels -- a streaming loop-closure run
+    asks for frame i + 1 next (demo3_lcd.py:88-123), and its single-scan leg (0.15 ms of latency-bound kernels) would otherwise
+    sit in front of its own heads with the GPU nearly idle.  Purely speculative: a missing file, or a different next request, and
+    the next call computes its frame as usual."""
+    try:
+      names = [str(int(current_frame_id) + 1).zfill(6)]
+    except (TypeError, ValueError):
+      return
+    self._drop_ahead()
+    self._readahead(names)
+    if self._ahead is None:
+      return
+    try:
+      if self._qa is None:
+        from .engine import QueryAhead
+        self._qa = QueryAhead(self.engine, self._weights, self._model_cfg)
+      with torch.cuda.stream(self._qa.stream):
+        x = self._inputs_device(names)          # copies + interleave on the side stream (consumes the read-ahead)
+      self._qa.submit(x, wait_current=False)
+      self._ahead_fv = names[0]
+    except Exception:
+      self._ahead_fv = None
+
+  def _drop_ahead(self) -> None:
+    if self._ahead_fv is not None:
+      self._qa.take()             # keeps the helper's in-flight count right; the result is ignored
+      self._ahead_fv = None
+
+  def _frame_features(self, name: str) -> torch.Tensor:
+    """(1, 360, 128) feature volume of frame `name` on the current stream: the side stream's result if that is the frame it was
+    given, a fresh leg otherwise -- the same kernels, the same bits either way."""
+    if self._ahead_fv == name:
+      self._ahead_fv = None
+      return self._qa.take()[0]
+    self._drop_ahead()
+    return self._leg_device([name])
+
   def infer_multiple(self, current_frame_id, reference_frame_id):
     """ Loop closing: current frame vs old frames (infer.py:162-203).  The current frame's feature
         volume is computed and appended (index == frame id); older ones must already be cached. """
-    filename = [str(current_frame_id).zfill(6)]
-    self.feature_volumes.extend_device(self._leg_device(filename))
+    self.feature_volumes.extend_device(self._frame_features(str(current_frame_id).zfill(6)))
 
     if len(reference_frame_id) > 0:
       pair_indizes = np.zeros((len(reference_frame_id), 2), dtype=int)
@@ -403,11 +445,7 @@ class Infer():
       n = len(self.feature_volumes)
       if pair_indizes.min() < 0 or pair_indizes.max() >= n:
         raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(pair_indizes.max()), n))
-      try:
-        ahead = [str(int(current_frame_id) + 1).zfill(6)]    # a streaming run asks for the next frame next
-      except (TypeError, ValueError):
-        ahead = None
-      overlap, yaw = self._run_heads(self.feature_volumes, pair_indizes, ahead)
+      overlap, yaw = self._run_heads(self.feature_volumes, pair_indizes, ahead=current_frame_id)
       return overlap.squeeze(), yaw
     else:
       return None
@@ -417,8 +455,7 @@ class Infer():
         (demo3_lcd.py:117-120) taken on the GPU, so only one record crosses PCIe instead of N scores.
         Returns (reference frame id, overlap, yaw) or None; caches the current frame like `infer_multiple`. """
     from .engine import decode_match
-    filename = [str(current_frame_id).zfill(6)]
-    self.feature_volumes.extend_device(self._leg_device(filename))
+    self.feature_volumes.extend_device(self._frame_features(str(current_frame_id).zfill(6)))
     if len(reference_frame_id) == 0:
       return None
     ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
@@ -431,7 +468,7 @@ class Infer():
     r = self._heads_device(self.feature_volumes, pair_indizes)
     ids = torch.from_numpy(ref.astype(np.int32)).to(self.engine.device)
     rec = self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=ids)
-    self._readahead([str(int(current_frame_id) + 1).zfill(6)])    # next frame's files, in the shadow of the kernels just enqueued
+    self._start_ahead(current_frame_id)     # next frame's files, copy and leg in the shadow of the kernels just enqueued
     return decode_match(rec)
 
   def infer_multiple_vs_multiple(self, file_names, first_idxs, second_idxs):

@@ -177,37 +177,43 @@ def test_c_abi_collective_one_rank():
     eng.close()
 
 
-def test_streaming_readahead_changes_nothing(tmp_path, fixture_npz):
-    """`infer_multiple(i, ...)` reads frame i + 1's files ahead, in the shadow of its head kernels (host plumbing of the demo3 loop,
-    demo3_lcd.py:88-123).  A run that hits the read-ahead, one that asks for other frames than the guessed ones, and one with the
-    read-ahead disabled must return the same bits; a guess that names a missing file must not surface as an error."""
+def test_streaming_lookahead_changes_nothing(tmp_path, fixture_npz):
+    """`infer_multiple(i, ...)` reads frame i + 1's files and runs its leg on a second context / stream in the shadow of frame i's head
+    kernels (host plumbing of the demo3 loop, demo3_lcd.py:88-123).  A run that hits the look-ahead, one with it disabled, and one
+    that then asks for something else must return the same bits; a guess that names a missing file must not surface as an error."""
     from overlapnet_amd.infer import Infer
     root = tmp_path / "data"
     _write_sequence(str(root), fixture_npz, 6)
     w = S.make_test_weights(4, seed=0)
 
-    def run(readahead):
+    def run(lookahead):
         inf = Infer(_config(root), weights=w)
-        if not readahead:
-            inf._readahead = lambda names: None
+        if not lookahead:
+            inf._start_ahead = lambda i: None
         out, hits = [], 0
         for i in range(6):
-            guess = getattr(inf, "_ahead", None)
-            hits += int(guess is not None and guess[0] == ("%06d" % i,))
+            hits += int(inf._ahead_fv == "%06d" % i)
             out.append(inf.infer_multiple(i, list(range(i))))
-        return out, hits
+        return out, hits, inf
 
-    a, hits_a = run(True)      # frames 2 .. 5 come out of the read-ahead (frame 0's call has no heads to hide behind; frame 6 does
-    b, hits_b = run(False)     # not exist: that guess fails silently)
-    assert hits_a == 4 and hits_b == 0
+    a, hits_a, inf_a = run(True)     # frames 2 .. 5 come from the side stream (frame 0's call has no heads to hide behind; frame 6 does
+    b, hits_b, _ = run(False)        # not exist: that guess fails silently)
+    assert hits_a == 4 and hits_b == 0 and inf_a._ahead_fv is None
     for i in range(1, 6):
         assert np.array_equal(a[i][0], b[i][0]) and np.array_equal(a[i][1], b[i][1])
-    # a guess that is wrong: frame 1's call reads frame 2 ahead, but frame 4's files are then asked for through create_feature_volumes
+    assert torch.equal(inf_a.feature_volumes.device_features, run(False)[2].feature_volumes.device_features)
+    # a guess that is wrong: frame 1's call starts frame 2, but the next requests are something else
     inf = Infer(_config(root), weights=w)
     inf.infer_multiple(0, [])
     inf.infer_multiple(1, [0])
-    assert inf._ahead is not None and inf._ahead[0] == ("000002",)
-    fv4 = inf.create_feature_volumes(["000004"])
+    assert inf._ahead_fv == "000002"
     ref = Infer(_config(root), weights=w)
-    ref._readahead = lambda names: None
-    assert np.array_equal(fv4, ref.create_feature_volumes(["000004"])) and inf._ahead is None
+    ref._start_ahead = lambda i: None
+    assert np.array_equal(inf.create_feature_volumes(["000004"]), ref.create_feature_volumes(["000004"]))
+    inf.feature_volumes = []                           # the reference's way to reset the cache; the pending frame 2 is dropped
+    ref.feature_volumes = []
+    for i in (0, 1, 2):
+        ra, rb = inf.infer_multiple(i, list(range(i))), ref.infer_multiple(i, list(range(i)))
+        assert (ra is None and rb is None) or (np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]))
+    got = inf.infer_best_match(3, [0, 1, 2], overlap_thres=0.0)      # frame 3 comes from the side stream here too
+    assert got == ref.infer_best_match(3, [0, 1, 2], overlap_thres=0.0)

@@ -956,3 +956,46 @@ def test_other_conv1sizes_run_the_general_path(s, tmp_path, fixture_npz):
         ofv = O.leg_forward(np.stack(imgs), w, cfg, np.float64)
         o_ov, o_yaw, _, _ = O.heads_forward(ofv[[0, 1]], ofv[[2, 2]], w, conv1size=s)
         assert np.max(np.abs(res[0] - o_ov)) <= 1e-4 and np.array_equal(res[1], o_yaw)
+
+
+def test_query_ahead_gives_the_bits_of_the_serial_order(engines, fixture_images):
+    """`QueryAhead` (leg + spectrum of the next query on a second context and stream, beside the current query's head kernels:
+    the streaming form of `Infer.infer_multiple`, infer.py:162-203) returns exactly what `engine.leg` / `engine.spectrum` return on
+    the caller's stream, for a sequence of different queries, in both submit / take orders, and refuses a third query in flight."""
+    from overlapnet_amd.engine import QueryAhead
+    from overlapnet_amd._lib import OvnError
+    e = engines[4]
+    w = S.make_test_weights(4, seed=0)
+    imgs = torch.from_numpy(fixture_images(4)).cuda()
+    queries = [imgs[i % imgs.shape[0]:i % imgs.shape[0] + 1].roll(37 * i, dims=2).contiguous() for i in range(6)]
+    cands = e.leg(torch.cat(queries[:4]))
+    cspec, cdc = e.spectrum(cands), e.delta_cache(cands)
+    want = []
+    for q in queries:
+        fv = e.leg(q)
+        sp = e.spectrum(fv)
+        r = e.heads(cands, fv, spec_l=cspec, spec_r=sp, dcache_l=cdc)
+        want.append((fv.clone(), sp.clone(), r["overlap"].clone(), r["yaw"].clone()))
+    qa = QueryAhead(e, w, S.REFERENCE_MODEL_CFG)
+    try:
+        qa.submit(queries[0])
+        for k, q in enumerate(queries):
+            if k + 1 < len(queries):
+                qa.submit(queries[k + 1])             # beside the heads of query k
+            fv, sp = qa.take()
+            r = e.heads(cands, fv, spec_l=cspec, spec_r=sp, dcache_l=cdc)
+            assert torch.equal(fv, want[k][0]) and torch.equal(sp, want[k][1])
+            assert torch.equal(r["overlap"], want[k][2]) and torch.equal(r["yaw"], want[k][3])
+        with pytest.raises(OvnError, match="nothing submitted"):
+            qa.take()
+        for k, q in enumerate(queries[:3]):            # take-then-submit order, one in flight
+            qa.submit(q)
+            fv, sp = qa.take()
+            assert torch.equal(fv, want[k][0]) and torch.equal(sp, want[k][1])
+        qa.submit(queries[0])
+        qa.submit(queries[1])
+        with pytest.raises(OvnError, match="already in flight"):
+            qa.submit(queries[2])
+        assert torch.equal(qa.take()[0], want[0][0]) and torch.equal(qa.take()[0], want[1][0])
+    finally:
+        qa.close()

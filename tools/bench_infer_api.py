@@ -3,7 +3,8 @@
 
 BASELINE.json configs[2] emulated (KITTI 07 is not in the tree): F synthetic frames; frame i goes through the leg
 and is compared with ALL previous frames (ungated: F (F-1) / 2 pairs), feature / spectrum caches resident in HBM.
-  * engine_sweep: device-resident input images, `OvnEngine` calls, decision on the device (one 16-byte record per frame);
+  * engine_sweep: device-resident input images, `OvnEngine` calls (next frame's leg beside the current frame's heads: `QueryAhead`),
+                  decision on the device (one 16-byte record per frame);
   * api_sweep:    depth / normal .npy files laid out like demo1 writes them, `Infer.infer_multiple(i, [0 .. i-1])` (or
                   `infer_best_match`) per frame: np.load, H2D, leg, spectrum, both heads, result back on the host.
     python tools/bench_infer_api.py [--frames 1101] [--mode multiple|best_match]
@@ -23,9 +24,11 @@ from tools import synthetic as S  # noqa: E402
 
 
 def engine_sweep(frames: int = 1101, C: int = 4):
-    from overlapnet_amd.engine import OvnEngine, decode_match
+    from overlapnet_amd.engine import OvnEngine, QueryAhead, decode_match
     eng = OvnEngine(64, 900, C)
-    eng.load_weights(S.make_test_weights(C, 0), S.REFERENCE_MODEL_CFG)
+    w = S.make_test_weights(C, 0)
+    eng.load_weights(w, S.REFERENCE_MODEL_CFG)
+    qa = QueryAhead(eng, w, S.REFERENCE_MODEL_CFG)     # frame i + 1's leg beside frame i's head kernels (what Infer does too)
     dev = eng.device
     imgs = torch.from_numpy(S.candidate_images(128, C, seed=3)).to(dev)      # 128 distinct synthetic scans, reused cyclically
     feats = torch.empty((frames, 360, 128), dtype=torch.float32, device=dev)
@@ -34,10 +37,13 @@ def engine_sweep(frames: int = 1101, C: int = 4):
 
     def run():
         found = 0
+        qa.submit(imgs[0:1])
         for i in range(frames):
-            q = imgs[i % 128:i % 128 + 1]
-            eng.leg(q, out=feats[i:i + 1])
-            eng.spectrum(feats[i:i + 1], out=specs[i:i + 1])
+            if i + 1 < frames:
+                qa.submit(imgs[(i + 1) % 128:(i + 1) % 128 + 1])
+            fv, sp = qa.take()
+            feats[i:i + 1].copy_(fv)
+            specs[i:i + 1].copy_(sp)
             eng.delta_cache(feats[i:i + 1], out=dcs[i:i + 1])
             if i == 0:
                 continue
@@ -51,6 +57,7 @@ def engine_sweep(frames: int = 1101, C: int = 4):
     found = run()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    qa.close()
     eng.close()
     pairs = frames * (frames - 1) // 2
     return {"frames": frames, "pairs": pairs, "seconds": dt, "frames_per_s": frames / dt, "pairs_per_s": pairs / dt,
