@@ -999,3 +999,39 @@ def test_query_ahead_gives_the_bits_of_the_serial_order(engines, fixture_images)
         assert torch.equal(qa.take()[0], want[0][0]) and torch.equal(qa.take()[0], want[1][0])
     finally:
         qa.close()
+
+
+def test_query_ahead_soak_under_a_full_head_sweep(engines, fixture_images):
+    """120 streamed queries, the heads of each a 1-vs-1024 sweep that keeps every CU busy while the next query's leg runs beside it:
+    every feature volume, spectrum and score equals the serial order's (a missing event or a reused buffer would show up here)."""
+    from overlapnet_amd.engine import QueryAhead
+    e = engines[4]
+    w = S.make_test_weights(4, seed=0)
+    imgs = torch.from_numpy(fixture_images(4)).cuda()
+    queries = [imgs[i % imgs.shape[0]:i % imgs.shape[0] + 1].roll(53 * i + 7, dims=2).contiguous() for i in range(8)]
+    cands = e.leg(torch.cat(queries)).repeat(128, 1, 1).contiguous()          # 1024 candidates
+    cspec, cdc = e.spectrum(cands), e.delta_cache(cands)
+    want = []
+    for q in queries:
+        fv = e.leg(q)
+        sp = e.spectrum(fv)
+        r = e.heads(cands, fv, spec_l=cspec, spec_r=sp, dcache_l=cdc)
+        want.append((fv.clone(), sp.clone(), r["overlap"].clone(), r["yaw"].clone()))
+    qa = QueryAhead(e, w, S.REFERENCE_MODEL_CFG)
+    bad = 0
+    try:
+        n = 120
+        qa.submit(queries[0])
+        results = []
+        for k in range(n):
+            if k + 1 < n:
+                qa.submit(queries[(k + 1) % 8])
+            fv, sp = qa.take()
+            r = e.heads(cands, fv, spec_l=cspec, spec_r=sp, dcache_l=cdc)
+            results.append((fv.clone(), sp.clone(), r["overlap"], r["yaw"]))     # clones are ordered on the consumer's stream
+        torch.cuda.synchronize()
+        for k, got in enumerate(results):
+            bad += int(not all(torch.equal(a, b) for a, b in zip(got, want[k % 8])))
+    finally:
+        qa.close()
+    assert bad == 0
