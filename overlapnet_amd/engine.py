@@ -463,7 +463,10 @@ class QueryAhead:
 
     Same kernels, same bits as `engine.leg` / `engine.spectrum` on the caller's stream (tests/test_gpu_parity.py)."""
 
-    def __init__(self, engine: OvnEngine, weights: Dict[str, np.ndarray], model_cfg: Optional[dict] = None):
+    def __init__(self, engine: OvnEngine, weights: Dict[str, np.ndarray], model_cfg: Optional[dict] = None,
+                 with_delta_cache: bool = False):
+        """with_delta_cache: also compute the query's Delta cache row (`take_all`), for callers that cache every query as a future
+        candidate (Infer.infer_multiple)."""
         self.main = engine
         self.side = OvnEngine(engine.in_h, engine.in_w, engine.in_c, device=engine.device_index)
         self.side.load_weights(weights, model_cfg)
@@ -474,6 +477,8 @@ class QueryAhead:
             self.stream = torch.cuda.Stream(device=dev)
             self._fv = [torch.empty((1, FEAT_W, FEAT_C), dtype=torch.float32, device=dev) for _ in range(2)]
             self._spec = [torch.empty((1, FEAT_C, engine.SPEC_W), dtype=torch.float32, device=dev) for _ in range(2)]
+            self._dc = ([torch.empty((1, engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev) for _ in range(2)]
+                        if with_delta_cache and engine.has_delta_cache else None)
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._released = [None, None]      # recorded on the consumer's stream when a slot's results are handed out again
         self._submitted = 0
@@ -493,6 +498,8 @@ class QueryAhead:
         with torch.cuda.stream(self.stream):
             self.side.leg(image, out=self._fv[slot])
             self.side.spectrum(self._fv[slot], out=self._spec[slot])
+            if self._dc is not None:
+                self.side.delta_cache(self._fv[slot], out=self._dc[slot])
             self._ready[slot].record(self.stream)
         image.record_stream(self.stream)
         self._submitted += 1
@@ -510,7 +517,13 @@ class QueryAhead:
         ev.record(cur)
         self._released[other] = ev
         self._taken += 1
+        self._last = slot
         return self._fv[slot], self._spec[slot]
+
+    def take_all(self):
+        """take() plus the Delta cache row (None unless built with `with_delta_cache` on a head geometry that has one)."""
+        fv, spec = self.take()
+        return fv, spec, (self._dc[self._last] if self._dc is not None else None)
 
     def close(self) -> None:
         self.stream.synchronize()

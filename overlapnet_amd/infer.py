@@ -47,7 +47,9 @@ class FeatureVolumeCache(object):
     self._min_capacity = max(1, int(min_capacity))
 
   # -- device side ---------------------------------------------------------------------------------
-  def extend_device(self, fv: torch.Tensor) -> None:
+  def extend_device(self, fv: torch.Tensor, spec: Optional[torch.Tensor] = None, dc: Optional[torch.Tensor] = None) -> None:
+    """Append k volumes; their spectra / Delta cache rows are computed here unless the caller already has them (the streaming path
+    computes them beside the previous frame's head kernels)."""
     k = fv.shape[0]
     if self._fv is None or self._n + k > self._fv.shape[0]:
       cap = max(self._min_capacity, self._n + k if self._fv is None else 2 * (self._n + k))
@@ -62,9 +64,15 @@ class FeatureVolumeCache(object):
           nd[:self._n].copy_(self._dc[:self._n])
       self._fv, self._spec, self._dc = nf, ns, nd
     self._fv[self._n:self._n + k].copy_(fv)
-    self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
+    if spec is not None:
+      self._spec[self._n:self._n + k].copy_(spec)
+    else:
+      self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
     if self._engine.has_delta_cache:
-      self._engine.delta_cache(self._fv[self._n:self._n + k], out=self._dc[self._n:self._n + k])
+      if dc is not None:
+        self._dc[self._n:self._n + k].copy_(dc)
+      else:
+        self._engine.delta_cache(self._fv[self._n:self._n + k], out=self._dc[self._n:self._n + k])
     self._n += k
 
   @property
@@ -411,7 +419,7 @@ class Infer():
     try:
       if self._qa is None:
         from .engine import QueryAhead
-        self._qa = QueryAhead(self.engine, self._weights, self._model_cfg)
+        self._qa = QueryAhead(self.engine, self._weights, self._model_cfg, with_delta_cache=True)
       with torch.cuda.stream(self._qa.stream):
         x = self._inputs_device(names)          # copies + interleave on the side stream (consumes the read-ahead)
       self._qa.submit(x, wait_current=False)
@@ -424,19 +432,21 @@ class Infer():
       self._qa.take()             # keeps the helper's in-flight count right; the result is ignored
       self._ahead_fv = None
 
-  def _frame_features(self, name: str) -> torch.Tensor:
-    """(1, 360, 128) feature volume of frame `name` on the current stream: the side stream's result if that is the frame it was
-    given, a fresh leg otherwise -- the same kernels, the same bits either way."""
+  def _cache_frame(self, name: str) -> None:
+    """Append frame `name` to the feature-volume cache on the current stream: the side stream's feature volume, spectrum and Delta
+    cache row if that is the frame it was given, a fresh leg (+ spectrum + row) otherwise -- the same kernels, the same bits."""
     if self._ahead_fv == name:
       self._ahead_fv = None
-      return self._qa.take()[0]
+      fv, spec, dc = self._qa.take_all()
+      self.feature_volumes.extend_device(fv, spec=spec, dc=dc)
+      return
     self._drop_ahead()
-    return self._leg_device([name])
+    self.feature_volumes.extend_device(self._leg_device([name]))
 
   def infer_multiple(self, current_frame_id, reference_frame_id):
     """ Loop closing: current frame vs old frames (infer.py:162-203).  The current frame's feature
         volume is computed and appended (index == frame id); older ones must already be cached. """
-    self.feature_volumes.extend_device(self._frame_features(str(current_frame_id).zfill(6)))
+    self._cache_frame(str(current_frame_id).zfill(6))
 
     if len(reference_frame_id) > 0:
       pair_indizes = np.zeros((len(reference_frame_id), 2), dtype=int)
@@ -455,7 +465,7 @@ class Infer():
         (demo3_lcd.py:117-120) taken on the GPU, so only one record crosses PCIe instead of N scores.
         Returns (reference frame id, overlap, yaw) or None; caches the current frame like `infer_multiple`. """
     from .engine import decode_match
-    self.feature_volumes.extend_device(self._frame_features(str(current_frame_id).zfill(6)))
+    self._cache_frame(str(current_frame_id).zfill(6))
     if len(reference_frame_id) == 0:
       return None
     ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)

@@ -201,7 +201,10 @@ def test_streaming_lookahead_changes_nothing(tmp_path, fixture_npz):
     assert hits_a == 4 and hits_b == 0 and inf_a._ahead_fv is None
     for i in range(1, 6):
         assert np.array_equal(a[i][0], b[i][0]) and np.array_equal(a[i][1], b[i][1])
-    assert torch.equal(inf_a.feature_volumes.device_features, run(False)[2].feature_volumes.device_features)
+    fa, fb = inf_a.feature_volumes, run(False)[2].feature_volumes
+    assert torch.equal(fa.device_features, fb.device_features) and torch.equal(fa.device_spectra, fb.device_spectra)
+    used = 360 * 128 + 24 * 128 + 4          # words | linear term | {max, min, 0, 0}; the rest of a row is alignment padding, never written
+    assert torch.equal(fa.device_delta_cache[:, :used], fb.device_delta_cache[:, :used])
     # a guess that is wrong: frame 1's call starts frame 2, but the next requests are something else
     inf = Infer(_config(root), weights=w)
     inf.infer_multiple(0, [])
