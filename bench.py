@@ -439,7 +439,8 @@ def main():
                      "mfma_flops_per_algorithmic_flop": 3 if args.head_precision == "f16x3" else 1,
                      "frac_executed": (3 if args.head_precision == "f16x3" else 1) * achieved / peak,
                      "delta_total_ms": sum(prof[k][0] / max(prof[k][1], 1) for k in ("delta_prep", "delta_c12", "delta_c2") if k in prof),
-                     "note": rl_note},
+                     "note": rl_note + ("; the next query's leg kernels run on a second stream beside this kernel (QueryAhead): its event "
+                                        "time includes the CUs they take at its round boundaries" if qa is not None else "")},
         "kernels": kernel_table(prof),
         "head_hbm_gbps_algorithmic": (pairs / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
     }
