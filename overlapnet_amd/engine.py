@@ -491,6 +491,10 @@ class QueryAhead:
         if self._submitted - self._taken >= 2:
             raise _lib.OvnError("QueryAhead.submit: two queries are already in flight, take() one first")
         slot = self._submitted & 1
+        if self.side.leg_precision != self.main.leg_precision:       # follow the main engine's arithmetic (same bits as engine.leg)
+            self.side.set_leg_precision(self.main.leg_precision)
+        if self.side.head_precision != self.main.head_precision:
+            self.side.set_head_precision(self.main.head_precision)
         if wait_current:
             self.stream.wait_stream(torch.cuda.current_stream(self.main.device))   # the image belongs to the caller's stream
         if self._released[slot] is not None:
