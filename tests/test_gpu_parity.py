@@ -1035,3 +1035,34 @@ def test_query_ahead_soak_under_a_full_head_sweep(engines, fixture_images):
     finally:
         qa.close()
     assert bad == 0
+
+
+@pytest.mark.parametrize("C,mode", [(1, "f16x3"), (5, "f16x3"), (4, "f32")])
+def test_query_ahead_other_channel_counts_and_fp32_mode(engines, fixture_images, C, mode):
+    """The second context of `QueryAhead` is built like the first: other input channel counts (the generic first-layer kernel, the
+    absmax pass) and the all-fp32 arithmetic give the serial order's bits too."""
+    from overlapnet_amd.engine import QueryAhead
+    e = engines[C]
+    w = S.make_test_weights(C, seed=0)
+    imgs = torch.from_numpy(fixture_images(C)).cuda()
+    queries = [imgs[i % imgs.shape[0]:i % imgs.shape[0] + 1].roll(41 * i, dims=2).contiguous() for i in range(3)]
+    e.set_leg_precision(mode)
+    e.set_head_precision(mode)
+    try:
+        want = []
+        for q in queries:
+            fv = e.leg(q)
+            want.append((fv.clone(), e.spectrum(fv).clone()))
+        qa = QueryAhead(e, w, S.REFERENCE_MODEL_CFG)
+        try:
+            qa.submit(queries[0])
+            for k in range(3):
+                if k + 1 < 3:
+                    qa.submit(queries[k + 1])
+                fv, sp = qa.take()
+                assert torch.equal(fv, want[k][0]) and torch.equal(sp, want[k][1])
+        finally:
+            qa.close()
+    finally:
+        e.set_leg_precision("f16x3")
+        e.set_head_precision(DEFAULT_HEAD)
