@@ -581,7 +581,27 @@ def main():
                 q_step()
             torch.cuda.synchronize()
             lat["n%d" % n_c] = {"ms_per_query": 1e3 * (time.perf_counter() - t0) / 50}
-        lat["note"] = "host wall clock per query incl. the device-to-host read of the decision; N = 1 is BASELINE configs[0] (demo2's single pair)"
+            if qa is not None:
+                # the same queries as a STREAM (a recorded sequence, demo3_lcd.py:88-123): query k + 1's leg runs on the second context
+                # beside query k's heads; the host still reads every decision before it enqueues the next heads
+                def q_stream():
+                    fv, sp = qa.take()
+                    r = eng.heads(cands[:n_c], fv, spec_l=cand_spec[:n_c], spec_r=sp,
+                                  dcache_l=cand_dc[:n_c] if cand_dc is not None else None)
+                    rec = eng.best_match(r["overlap"], r["yaw"], 0.3)
+                    qa.submit(query_img, wait_current=False)     # the next query's image is resident: its leg need not wait for these heads
+                    return decode_match(rec)
+                for _ in range(5):
+                    q_stream()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(50):
+                    q_stream()
+                torch.cuda.synchronize()
+                lat["n%d" % n_c]["ms_per_query_streamed"] = 1e3 * (time.perf_counter() - t0) / 50
+        lat["note"] = ("host wall clock per query incl. the device-to-host read of the decision; N = 1 is BASELINE configs[0] (demo2's single "
+                       "pair); ms_per_query = one isolated query (leg, spectrum, heads, decision back to back); ms_per_query_streamed = per "
+                       "query of a stream whose next leg runs beside the current heads (QueryAhead), decision still read every query")
         out["latency"] = lat
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, P)
