@@ -39,7 +39,7 @@ typedef struct ovn_ctx ovn_ctx;
 #define OVN_ERR_STATE 3    /* call order (weights missing ...)  */
 
 /* ABI version of this header; bumped on any signature change. */
-#define OVN_ABI_VERSION 2
+#define OVN_ABI_VERSION 3
 int ovn_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -191,6 +191,14 @@ int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_de
  * (src/utils/utils.py:137-186 gen_normal_map). */
 int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,
                 float* normal_dev, void* stream);
+
+/* The per-point part of range_projection alone (src/utils/utils.py:75-104), exactly as ovn_project's scatter kernel evaluates it:
+ * for each of n float32 points (x,y,z,*) yaw = -np.arctan2(y, x), pitch = np.arcsin(z / depth) with NumPy's float32 results
+ * (csrc/svml_f32.h) and the pixel py * proj_w + px the point falls into (-1 for a point the range filter drops).  Outputs may
+ * be NULL.  A validation entry: lets a test compare the two angle functions with the reference's NumPy on millions of points. */
+int ovn_projection_angles(ovn_ctx* ctx, const float* points_dev, int64_t n_points, int proj_h, int proj_w, double fov_up_deg,
+                          double fov_down_deg, double max_range, float* yaw_dev, float* pitch_dev, int32_t* pixel_dev,
+                          void* stream);
 
 /* Ground-truth overlap labels (src/utils/com_overlap_yaw.py:28-46), the producer of the training / evaluation targets.
  * ovn_gt_range_images: range images (n, H, W) f32 (-1 = empty) of n scans moved by p' = inv_cur_pose . (ref_pose[s] . p)

@@ -10,7 +10,10 @@ PARITY STATUS
   * Preprocessing (`range_projection`, `gen_normal_map`): PINNED.  `tests/golden/kitti_preprocess.npz`
     was produced by running the reference's own `src/utils/utils.py` in the build container and was
     asserted equal to the `.npy` outputs the reference ships (`data/preprocess_data_demo/...`);
-    `tests/test_oracle_preprocess.py` checks this module against it bit-for-bit.
+    `tests/golden/preprocess_transformed.npz` holds the reference's outputs for 24 rotated / translated / tilted copies of the
+    two scans; `tests/test_oracle_preprocess.py` checks this module against both bit-for-bit.  The float32 `arctan2` /
+    `arcsin` of `utils.py:86-87` live in NumPy -> Intel SVML on the generating machine: restated in oracle/svml_f32.c and
+    pinned against NumPy itself (tests/test_oracle_svml.py).
   * Neural path (leg, Delta head, correlation head): PARITY UNPINNED.  The arithmetic lives in
     TensorFlow/Keras (requirements.txt:4-5: tensorflow-gpu==2.5.2, keras==2.1.5), neither of which is
     installable here, the pretrained `model_geo.weight` is not in the tree (.gitignore:9), and the
@@ -44,7 +47,7 @@ F64 = np.float64
 
 
 def range_projection(points: np.ndarray, fov_up: float = 3.0, fov_down: float = -25.0, proj_H: int = 64,
-                     proj_W: int = 900, max_range: float = 50.0, trig64: bool = False):
+                     proj_W: int = 900, max_range: float = 50.0, trig64: bool = False, trig: Optional[str] = None):
     """Spherical projection, reference `src/utils/utils.py:59-134`.
 
     depth = ||xyz||_2 in float32 (`:75`), keep 0 < depth < max_range (`:76-77`), yaw = -atan2(y,x),
@@ -55,8 +58,13 @@ def range_projection(points: np.ndarray, fov_up: float = 3.0, fov_down: float = 
     Equal-depth ties are undefined in the reference (unstable argsort); lowest index wins here.
     Returns (range (H,W) f32, vertex (H,W,4) f32, intensity (H,W) f32, idx (H,W) i32); empty = -1.
 
-    trig64=True evaluates atan2/asin in float64 and rounds to float32 (what the HIP kernel does);
-    the default keeps NumPy's float32 functions as the reference does.
+    `trig` selects how the two float32 angle functions of `:86-87` are evaluated:
+      'svml'  (default) the restatement of the SVML kernels NumPy's float32 arctan2 / arcsin run on AVX512_SKX x86-64 CPUs
+              (oracle/svml_f32.c: same bits as NumPy on the machine the golden vectors come from, on any host; what the HIP
+              kernel computes since round 4);
+      'numpy' this host's NumPy float32 functions, literally what the reference calls (CPU-dependent: SVML, or libm elsewhere);
+      'f64'   float64 functions rounded once to float32 (the HIP kernel of rounds 1-3; differs from the reference on a few
+              pixels per million points).  `trig64=True` is the old spelling of 'f64'.
     """
     pts = np.ascontiguousarray(points, dtype=F32).reshape(-1, 4)
     up = fov_up / 180.0 * np.pi
@@ -66,12 +74,19 @@ def range_projection(points: np.ndarray, fov_up: float = 3.0, fov_down: float = 
     depth = np.sqrt((x * x + y * y) + z * z)  # float32, same association as np.linalg.norm(axis=1)
     keep = (depth > 0) & (depth < max_range)
     x, y, z, inten, depth = x[keep], y[keep], z[keep], inten[keep], depth[keep]
-    if trig64:
+    trig = trig or ("f64" if trig64 else "svml")
+    if trig == "f64":
         yaw = (-np.arctan2(y.astype(F64), x.astype(F64))).astype(F32)
         pitch = np.arcsin((z / depth).astype(F64)).astype(F32)
-    else:
+    elif trig == "numpy":
         yaw = -np.arctan2(y, x)
         pitch = np.arcsin(z / depth)
+    elif trig == "svml":
+        from oracle import build_oracle
+        yaw = -build_oracle.svml_arctan2(y, x)
+        pitch = build_oracle.svml_arcsin(z / depth)
+    else:
+        raise ValueError("trig must be 'svml', 'numpy' or 'f64'")
     px = F32(0.5) * (yaw / F32(np.pi) + F32(1.0))
     py = F32(1.0) - (pitch + F32(abs(down))) / F32(fov)
     px = px * F32(proj_W)

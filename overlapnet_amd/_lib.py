@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libovn_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -43,6 +43,7 @@ SIGNATURES = {
     "ovn_project": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double,
                               C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp]),
     "ovn_normals": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "ovn_projection_angles": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _vp, _vp, _vp, _vp]),
     "ovn_gt_range_images": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int64, _vp, _vp, C.c_int, C.c_int, C.c_double, C.c_double,
                                       C.c_double, _vp, _vp]),
     "ovn_gt_overlap_counts": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),

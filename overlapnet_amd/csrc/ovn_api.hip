@@ -527,7 +527,9 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
       if (fused) {   // times its prepare kernels, the contraction kernel and c_conv2 separately
         unsigned* o2max = nullptr;
         float* part = o3 + (size_t)q0 * 3;
-        rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff), dcache_l);
+        rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff),
+                                          // a cache row belongs to a CANDIDATE: without an index list it moves with the feature pointer
+                                          dcache_l ? (lidx ? dcache_l : dcache_l + (size_t)p0 * OVN_DELTA_CACHE_ELEMS) : nullptr);
         if (rc) return rc;
         if (p0 == 0) ctx->dbg_o2max = o2max;
         {
@@ -656,6 +658,18 @@ int ovn_project(ovn_ctx* ctx, const float* points_dev, const int64_t* offsets_de
   return ovn_project_forward(ctx, points_dev, offsets_dev, n_scans, max_points_per_scan, proj_h, proj_w, fov_up_deg,
                              fov_down_deg, max_range, range_dev, vertex_dev, intensity_dev, idx_dev, normal_dev,
                              stacked_dev, use_depth, use_normals, use_intensity, (hipStream_t)stream);
+}
+
+int ovn_projection_angles(ovn_ctx* ctx, const float* points_dev, int64_t n_points, int proj_h, int proj_w, double fov_up_deg,
+                          double fov_down_deg, double max_range, float* yaw_dev, float* pitch_dev, int32_t* pixel_dev,
+                          void* stream) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_projection_angles: ctx is NULL");
+  OVN_REQUIRE(n_points >= 0 && proj_h > 0 && proj_w > 0, OVN_ERR_ARG, "ovn_projection_angles: bad sizes");
+  if (n_points == 0) return OVN_OK;
+  OVN_REQUIRE(points_dev != nullptr, OVN_ERR_ARG, "ovn_projection_angles: points is NULL");
+  OVN_ON_DEVICE(ctx->device);
+  return ovn_projection_angles_forward(points_dev, n_points, proj_h, proj_w, fov_up_deg, fov_down_deg, max_range, yaw_dev,
+                                       pitch_dev, pixel_dev, (hipStream_t)stream);
 }
 
 int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,

@@ -306,6 +306,8 @@ int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offset
                         float* normal, float* stacked, int use_depth, int use_normals, int use_intensity,
                         hipStream_t stream);
 
+int ovn_projection_angles_forward(const float* points, int64_t n, int H, int W, double fov_up_deg, double fov_down_deg,
+                                  double max_range, float* yaw, float* pitch, int32_t* pixel, hipStream_t stream);
 int ovn_normals_forward(const float* range, const float* vertex, int n_scans, int H, int W, float* normal,
                         hipStream_t stream);
 

@@ -387,6 +387,23 @@ class OvnEngine:
                        "ovn_normals")
         return out
 
+    def projection_angles(self, points: torch.Tensor, proj_h: int = 64, proj_w: int = 900, fov_up: float = 3.0,
+                          fov_down: float = -25.0, max_range: float = 50.0):
+        """(yaw, pitch, pixel) of every point of an (n, 4) float32 device tensor as the projection kernel evaluates them
+        (utils.py:75-104; pixel = -1 for points the range filter drops) -- validation entry, include/ovn_hip.h."""
+        if points.device != self.device or points.dtype != torch.float32 or not points.is_contiguous() or points.dim() != 2 \
+                or points.shape[1] != 4:
+            raise _lib.OvnError("projection_angles(): points must be a contiguous (n, 4) float32 tensor on %s" % self.device)
+        n = points.shape[0]
+        yaw = torch.empty(n, dtype=torch.float32, device=self.device)
+        pitch = torch.empty(n, dtype=torch.float32, device=self.device)
+        pix = torch.empty(n, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.ovn_projection_angles(self._h, _ptr(points), n, proj_h, proj_w, float(fov_up), float(fov_down),
+                                                      float(max_range), _ptr(yaw), _ptr(pitch), _ptr(pix), self._stream()),
+                       "ovn_projection_angles")
+        return yaw, pitch, pix
+
     def debug_head_activations(self, n: int):
         """(o2 (n,24,24,128), o3 (n,22,22,256)) left in scratch by the last heads() call -- test hook."""
         o2 = torch.empty((n, 24, 24, 128), dtype=torch.float32, device=self.device)
@@ -396,7 +413,7 @@ class OvnEngine:
                        "ovn_debug_head_activations")
         return o2, o3
 
-    def set_head_pipeline(self, chunk_pairs: int = 1024, sub_chunk_pairs: int = 0, streams: int = 1, yaw_on_side_stream: bool = True):
+    def set_head_pipeline(self, chunk_pairs: int = 1024, sub_chunk_pairs: int = 0, streams: int = 1, yaw_on_side_stream: bool = False):
         """Launch structure of the head calls (include/ovn_hip.h: ovn_set_head_pipeline); results do not depend on it."""
         _lib.check(self.lib.ovn_set_head_pipeline(self._h, int(chunk_pairs), int(sub_chunk_pairs), int(streams),
                                                   int(bool(yaw_on_side_stream))), "ovn_set_head_pipeline")

@@ -345,6 +345,85 @@ def test_projection_against_reference_golden(engines, fixture_npz, scan):
     assert np.array_equal(n2, nrm)
 
 
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_projection_on_24_transformed_clouds_against_the_reference(engines, fixture_npz):
+    """the HIP projection against outputs of the reference's OWN range_projection + gen_normal_map on 24 rotated /
+    translated / tilted copies of the two scans (tests/golden/preprocess_transformed.npz; clouds 0-11 are the ones bench.py's
+    fullstack leg feeds).  Gate: 0 differing RANGE pixels on every cloud (rounds 1-3: 12); the index image may differ only where
+    two points of a pixel have bit-identical minimal depth (the reference's unstable argsort, utils.py:108, picks either; lower
+    index here): 10 pixels of 1.38 M; every image equals the CPU oracle's (same tie rule) bit for bit, and on the clouds without
+    such a pixel the intensity and normal images carry the reference's hashes."""
+    from overlapnet_amd import preprocess as P
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess_transformed.npz"))
+    clouds = [S.transformed_cloud(fixture_npz, i) for i in range(S.N_TRANSFORMED)]
+    r = P.project_scans(clouds, engine=engines[4], want=("range", "vertex", "intensity", "idx", "normal"))
+    out = {k: v.cpu().numpy() for k, v in r.items()}
+    range_diffs, tie_diffs = [], []
+    for i, pts in enumerate(clouds):
+        assert _sha(pts) == str(g["sha_cloud_%d" % i])
+        gi = g["idx_%d" % i]
+        x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+        depth = np.sqrt((x * x + y * y) + z * z)
+        dk = depth[(depth > 0) & (depth < 50)]
+        g_rng = np.where(gi >= 0, dk[np.maximum(gi, 0)], np.float32(-1))
+        range_diffs.append(int((out["range"][i] != g_rng).sum()))
+        bad = np.argwhere(out["idx"][i] != gi)
+        tie_diffs.append(len(bad))
+        for (a, b) in bad:
+            assert dk[out["idx"][i][a, b]] == dk[gi[a, b]], "cloud %d pixel (%d, %d): different winner that is not a depth tie" % (i, a, b)
+        o_rng, o_vtx, o_int, o_idx = O.range_projection(pts)
+        assert np.array_equal(out["range"][i], o_rng) and np.array_equal(out["idx"][i], o_idx)
+        assert np.array_equal(out["intensity"][i], o_int) and np.array_equal(out["vertex"][i], o_vtx)
+        assert np.array_equal(out["normal"][i], O.gen_normal_map(o_rng, o_vtx))
+        if not len(bad):
+            assert _sha(out["range"][i]) == str(g["sha_range_%d" % i]) and _sha(out["intensity"][i]) == str(g["sha_intensity_%d" % i])
+            assert _sha(out["normal"][i]) == str(g["sha_normal_%d" % i])
+    print("differing range pixels per cloud vs the reference:", range_diffs, "| index pixels (exact depth ties):", tie_diffs)
+    assert sum(range_diffs) == 0 and sum(tie_diffs) == 10
+
+
+def test_projection_angles_have_numpys_float32_bits(engines, fixture_npz):
+    """The two angle functions of utils.py:86-87 on the GPU (csrc/svml_f32.h) against NumPy's own float32 results: the committed
+    vectors (arctan2 directly; arcsin through points built to hit given sines) and, through the pinned CPU restatement, every
+    point of two transformed clouds plus 2 M random points over a wide exponent range, quadrant edges and zero coordinates."""
+    from oracle import build_oracle as B
+    e = engines[4]
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "svml_f32_vectors.npz")) as z:
+        vx, vy, vat = z["x"], z["y"], z["atan2"]
+    ok = np.isfinite(vx) & np.isfinite(vy)
+    vx, vy, vat = vx[ok], vy[ok], vat[ok]
+    pts = np.zeros((len(vx), 4), np.float32)
+    pts[:, 0], pts[:, 1] = vx, vy
+    yaw, _, pix = (t.cpu().numpy() for t in e.projection_angles(torch.from_numpy(pts).cuda(), max_range=3.0e38))
+    keep = pix >= 0                        # (0,0,0) and overflowing depths are dropped by the range filter before any angle
+    assert keep.sum() > 0.75 * len(vx)
+    assert np.array_equal(yaw[keep].view(np.uint32), (-vat[keep]).view(np.uint32))
+    rng = np.random.default_rng(99)
+    n = 2_000_000
+    rnd = np.zeros((n, 4), np.float32)
+    rnd[:, :3] = (rng.uniform(-1, 1, (n, 3)) * np.exp(rng.uniform(-30, 30, (n, 1)))).astype(np.float32)
+    rnd[::7, 2] *= np.float32(30.0)        # steep points: the |sin| >= 0.5 branch of arcsin
+    rnd[::1001, 0] = 0
+    rnd[::1003, 1] = 0
+    rnd[::1007, 2] = 0
+    rnd[5::2002, 0] = -0.0
+    for cloud in (S.transformed_cloud(fixture_npz, 9), S.transformed_cloud(fixture_npz, 21), rnd):
+        yaw, pitch, pix = (t.cpu().numpy() for t in e.projection_angles(torch.from_numpy(np.ascontiguousarray(cloud)).cuda(), max_range=1.0e30))
+        x, y, zz = cloud[:, 0], cloud[:, 1], cloud[:, 2]
+        depth = np.sqrt((x * x + y * y) + zz * zz)
+        keep = (depth > 0) & (depth < np.float32(1.0e30))
+        assert np.array_equal(keep, pix >= 0)
+        o_yaw = -B.svml_arctan2(y[keep], x[keep])
+        o_pitch = B.svml_arcsin(zz[keep] / depth[keep])
+        assert np.array_equal(yaw[keep].view(np.uint32), o_yaw.view(np.uint32))
+        assert np.array_equal(pitch[keep].view(np.uint32), o_pitch.view(np.uint32))
+        assert (np.abs(zz[keep] / depth[keep]) >= 0.5).sum() > 100
+
+
 def test_projection_batch_ragged_and_edge_cases(engines, fixture_npz):
     from overlapnet_amd import preprocess as P
     p0, p1 = fixture_npz["points_0"], fixture_npz["points_1"]
@@ -359,9 +438,9 @@ def test_projection_batch_ragged_and_edge_cases(engines, fixture_npz):
     assert np.array_equal(r["normal"][0].cpu().numpy(), single0["normal"][0].cpu().numpy())
     assert np.array_equal(r["idx"][0].cpu().numpy(), single0["idx"][0].cpu().numpy())
     assert np.all(rng[1] == -1) and np.all(rng[3] == -1) and np.all(r["idx"][1].cpu().numpy() == -1)
-    o_rng, _, o_int, o_idx = O.range_projection(p1[:1000], trig64=True)
+    o_rng, _, o_int, o_idx = O.range_projection(p1[:1000])
     assert np.array_equal(rng[2], o_rng) and np.array_equal(r["idx"][2].cpu().numpy(), o_idx)
-    t_rng, _, t_int, t_idx = O.range_projection(tie, trig64=True)
+    t_rng, _, t_int, t_idx = O.range_projection(tie)
     assert np.array_equal(rng[4], t_rng) and np.array_equal(r["intensity"][4].cpu().numpy(), t_int)
     assert np.array_equal(r["idx"][4].cpu().numpy(), t_idx)
     assert (rng[4] > 0).sum() == 1 and rng[4].max() == 2.0
@@ -877,6 +956,37 @@ def test_delta_cache_gives_the_same_bits_and_falls_back_per_pair(engines):
     assert np.max(np.abs(got["overlap"].cpu().numpy() - o_ov)) <= 1e-4 and np.array_equal(got["yaw"].cpu().numpy(), o_yaw)
     with pytest.raises(Exception):
         e.heads(fvt, q, spec_l=spec, spec_r=e.spectrum(q), dcache_l=dc[:10].contiguous())
+
+
+def test_delta_cache_rows_follow_the_candidates_across_chunks(engines):
+    """A sweep WITHOUT an index list that spans several chunks / sub-chunks (two streams) must address candidate p's cache row, not
+    row p - chunk_start (the cache pointer did not move with the feature pointer): same bits as without the cache, and
+    within tolerance of the fp64 oracle for pairs beyond the first chunk."""
+    e = engines[4]
+    rng = np.random.default_rng(4242)
+    n = 300
+    fv = np.maximum(rng.normal(0.2, 1.0, size=(n, 360, 128)), 0).astype(np.float32)
+    fv *= rng.uniform(0.5, 2.0, size=(n, 1, 1)).astype(np.float32)      # rows differ in scale: a wrong row changes the result
+    fvt = torch.from_numpy(fv).cuda()
+    spec, dc = e.spectrum(fvt), e.delta_cache(fvt)
+    q = fvt[17:18].contiguous()
+    qs = e.spectrum(q)
+    saved = e.head_pipeline()
+    try:
+        e.set_head_pipeline(1024, 0, 1, False)
+        ref = e.heads(fvt, q, spec_l=spec, spec_r=qs, want_logit=True)
+        for cfg in ((128, 48, 2, True), (128, 0, 1, False), (100, 0, 1, False), (1024, 64, 2, False)):
+            e.set_head_pipeline(*cfg)
+            got = e.heads(fvt, q, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
+            torch.cuda.synchronize()
+            assert torch.equal(got["logit"], ref["logit"]) and torch.equal(got["overlap"], ref["overlap"]) and torch.equal(got["yaw"], ref["yaw"]), cfg
+        w = S.make_test_weights(4, seed=0)
+        sel = [130, 255, 299]
+        fv4 = fv[sel].reshape(-1, 1, 360, 128).astype(np.float64)
+        o_ov, o_yaw, _, _ = O.heads_forward(fv4, np.repeat(fv[17:18].reshape(1, 1, 360, 128).astype(np.float64), len(sel), axis=0), w)
+        assert np.max(np.abs(got["overlap"].cpu().numpy()[sel] - o_ov)) <= 1e-4 and np.array_equal(got["yaw"].cpu().numpy()[sel], o_yaw)
+    finally:
+        e.set_head_pipeline(*saved)
 
 
 def test_delta_cache_is_ignored_where_it_does_not_apply(engines):

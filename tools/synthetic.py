@@ -136,3 +136,56 @@ def sweep_query_image(channels: int = 4, fixture: Optional[Dict[str, np.ndarray]
     """(1, 64, 900, C): the query scan of the benchmark sweep = the first shipped scan, unshifted."""
     fx = fixture or load_fixture_images()
     return stack(fx["range_0"], fx["normal_0"], fx["intensity_0"], flags_of(channels))[None]
+
+
+# ---- transformed copies of the two shipped scans (tests/golden/preprocess_transformed.npz, bench.py's raw clouds) ----
+N_TRANSFORMED = 24
+
+
+def z_rotated(points: np.ndarray, cols: int) -> np.ndarray:
+    """The scan rotated about z by `cols` image columns (2 pi cols / 900), float32, one rounded multiply / subtract / add per
+    element exactly as bench.py does it on the device with torch (`c * x - s * y`, `s * x + c * y`)."""
+    th = 2.0 * np.pi * cols / 900.0
+    c, s = np.float32(np.cos(th)), np.float32(np.sin(th))
+    q = np.array(points, dtype=np.float32, copy=True)
+    x, y = points[:, 0].astype(np.float32), points[:, 1].astype(np.float32)
+    q[:, 0] = c * x - s * y
+    q[:, 1] = s * x + c * y
+    return q
+
+
+def transformed_cloud(fixture: Dict[str, np.ndarray], i: int) -> np.ndarray:
+    """Cloud i (0 .. N_TRANSFORMED-1) of the preprocessing parity set: 0-11 = bench.py's raw clouds (scan i mod 2 rotated about z
+    by 37 i mod 900 columns); 12-15 translations; 16-19 pitch / roll tilts; 20-23 rotation + tilt + translation.  Everything is
+    evaluated elementwise (float64 products summed left to right, rounded once to float32; the z rotations in float32 as the
+    bench does) so that every host produces the same bits."""
+    base = fixture["points_%d" % (i % 2)]
+    if i < 12:
+        return z_rotated(base, (37 * i) % 900)
+    k = i - 12
+    shifts = [(1.5, -0.7, 0.2), (-2.25, 0.4, -0.15), (0.3, 3.1, 0.05), (-0.8, -1.9, 0.3)]
+    tilts = [(2.0, 0.0), (-2.0, 0.0), (0.0, 3.0), (1.0, -3.0)]      # (pitch about y, roll about x) in degrees
+    yaw_cols = 0
+    t = (0.0, 0.0, 0.0)
+    pitch = roll = 0.0
+    if k < 4:
+        t = shifts[k]
+    elif k < 8:
+        pitch, roll = tilts[k - 4]
+    else:
+        t = shifts[k - 8]
+        pitch, roll = tilts[(k - 8 + 1) % 4]
+        yaw_cols = 113 * (k - 7)
+    p = base[:, :3].astype(np.float64)
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    a = 2.0 * np.pi * yaw_cols / 900.0
+    x, y = np.cos(a) * x - np.sin(a) * y, np.sin(a) * x + np.cos(a) * y
+    b = np.deg2rad(pitch)
+    x, z = np.cos(b) * x + np.sin(b) * z, -np.sin(b) * x + np.cos(b) * z
+    g = np.deg2rad(roll)
+    y, z = np.cos(g) * y - np.sin(g) * z, np.sin(g) * y + np.cos(g) * z
+    q = np.array(base, dtype=np.float32, copy=True)
+    q[:, 0] = (x + t[0]).astype(np.float32)
+    q[:, 1] = (y + t[1]).astype(np.float32)
+    q[:, 2] = (z + t[2]).astype(np.float32)
+    return q
