@@ -740,7 +740,8 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 template <int SPC, int ABL = 0>
 __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __restrict__ desc,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
-                                                             float* __restrict__ o1raw, int rot, int nsplit, int pair0) {
+                                                             float* __restrict__ o1raw, int rot, int nsplit, int pair0,
+                                                             const int32_t* __restrict__ lidx) {
   constexpr int CHB = SPC * STEP_BYTES;          // window chunk
   constexpr int CPS = S / SPC;                   // chunks per channel slice
   constexpr int NCH = 4 * CPS;                   // chunks per walk of K
@@ -788,9 +789,12 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
     if (wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
   }
 
-  // rotation of the K walk by the pair's index in the SWEEP (pair0 = index of this launch's first pair): the summation order of a
-  // pair, and with it the last bits of its result, does not depend on how the sweep is cut into launches
-  const int s0 = rot ? (((pair0 + pair) >> 3) & 3) : 0;
+  // rotation of the K walk by the CANDIDATE's slot in the left pool (its index-list entry, or its position in the pool when the
+  // sweep has no list; pair0 = slot of this launch's first pair): the summation order of a pair, and with it the last bits of its
+  // result, depends neither on how the sweep is cut into launches nor on where the candidate stands in an index list -- a shard
+  // of a pool whose first slot is a multiple of 32 (overlapnet_amd.distributed) reproduces the bits of the unsharded sweep
+  const int slot = lidx ? lidx[pair] : pair0 + pair;
+  const int s0 = rot ? ((slot >> 3) & 3) : 0;
   const int p_begin = part * (G / 2) / nsplit, p_end = (part + 1) * (G / 2) / nsplit;
   int cur = 0, rcur = 0;
   int chunk = CPS * s0;
@@ -1097,7 +1101,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), lds);              \
     if (rc) return rc;                                                                                                       \
     hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, desc,         \
-                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0);                      \
+                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx);                \
   }
 #ifdef OVN_ABLATE
     switch (getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0) {   // tools/experiments/c1_variants.py

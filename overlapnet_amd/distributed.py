@@ -16,18 +16,43 @@ import torch
 import torch.distributed as dist
 
 
-def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
-    """Contiguous block partition: the first (n mod world) ranks get one extra candidate."""
-    if world <= 0 or not (0 <= rank < world):
+SLOT_ALIGN = 32   # the Delta kernels' summation order is a function of (candidate slot mod 32): csrc/delta_head_f16x3.hip
+
+
+def shard_bounds(n: int, world: int, rank: int, align: int = 1) -> Tuple[int, int]:
+    """Contiguous block partition: the first (n mod world) ranks get one extra candidate.  align > 1: blocks of `align` candidates
+    are dealt out instead (every shard starts at a multiple of `align`; the last block may be short).  With align = SLOT_ALIGN a
+    candidate keeps its pool slot modulo 32 inside its shard, which makes the sharded sweep reproduce the unsharded one bit for
+    bit (the kernels' summation order follows that slot)."""
+    if world <= 0 or not (0 <= rank < world) or align < 1:
         raise ValueError("bad rank/world")
-    base, extra = divmod(int(n), world)
+    n = int(n)
+    if align > 1:
+        lo, hi = shard_bounds((n + align - 1) // align, world, rank)
+        return min(lo * align, n), min(hi * align, n)
+    base, extra = divmod(n, world)
     lo = rank * base + min(rank, extra)
     hi = lo + base + (1 if rank < extra else 0)
     return lo, hi
 
 
-def shard_sizes(n: int, world: int) -> List[int]:
-    return [shard_bounds(n, world, r)[1] - shard_bounds(n, world, r)[0] for r in range(world)]
+def shard_sizes(n: int, world: int, align: int = 1) -> List[int]:
+    return [shard_bounds(n, world, r, align)[1] - shard_bounds(n, world, r, align)[0] for r in range(world)]
+
+
+# ---- ownership of a GROWING cache (Infer.infer_multiple caches one frame per call, infer.py:184-185): block-cyclic --------------
+def frame_owner(frame_id, world: int, block: int = SLOT_ALIGN):
+    """Rank that keeps frame `frame_id`'s feature volume / spectrum / Delta row: blocks of `block` consecutive frames go round the
+    ranks.  Contiguous shards cannot be used for a cache that grows by one frame per query (their bounds would move); plain
+    round-robin would change a frame's slot modulo 32.  Works on ints and integer arrays."""
+    return (np.asarray(frame_id) // block) % world if not np.isscalar(frame_id) else (int(frame_id) // block) % world
+
+
+def frame_slot(frame_id, world: int, block: int = SLOT_ALIGN):
+    """Index of frame `frame_id` in its owner's local cache when frames arrive in order 0, 1, 2, ... (slot == frame_id mod block
+    modulo `block`, so the pair (frame, query) gets the unsharded sweep's bits)."""
+    f = np.asarray(frame_id) if not np.isscalar(frame_id) else int(frame_id)
+    return (f // (block * world)) * block + f % block
 
 
 def pack_scores(overlap: torch.Tensor, yaw: torch.Tensor) -> torch.Tensor:
@@ -39,19 +64,20 @@ def unpack_scores(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return buf[:, 0].contiguous().view(torch.float32), buf[:, 1].contiguous()
 
 
-def gather_scores(overlap: torch.Tensor, yaw: torch.Tensor, n_total: int, group=None, dst: int = 0
+def gather_scores(overlap: torch.Tensor, yaw: torch.Tensor, n_total: int, group=None, dst: int = 0, align: int = 1
                   ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
     """Gather the per-rank (overlap, yaw) shards, in candidate order, on rank `dst` (None elsewhere).
     A single fixed-size collective: shards are padded to the largest shard size."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    sizes = shard_sizes(n_total, world)
+    sizes = shard_sizes(n_total, world, align)
     if overlap.numel() != sizes[rank]:
         raise ValueError("rank %d holds %d scores, its shard has %d" % (rank, overlap.numel(), sizes[rank]))
     m = max(sizes) if sizes else 0
     payload = torch.zeros((m, 2), dtype=torch.int32, device=overlap.device)
     if overlap.numel():
         payload[:overlap.numel()] = pack_scores(overlap, yaw)
+    payload = _comm_device(payload, group)      # RCCL gathers device tensors, gloo host tensors
     if rank == dst:
         bufs = [torch.empty_like(payload) for _ in range(world)]
         dist.gather(payload, bufs, dst=dst, group=group)
@@ -62,13 +88,43 @@ def gather_scores(overlap: torch.Tensor, yaw: torch.Tensor, n_total: int, group=
 
 
 def sweep_one_vs_n(score_fn: Callable[[int, int], Tuple[torch.Tensor, torch.Tensor]], n_total: int, group=None,
-                   dst: int = 0):
+                   dst: int = 0, align: int = 1):
     """Run `score_fn(lo, hi)` -> (overlap, yaw) on this rank's block of the candidate pool and gather."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    lo, hi = shard_bounds(n_total, world, rank)
+    lo, hi = shard_bounds(n_total, world, rank, align)
     ov, yw = score_fn(lo, hi)
-    return gather_scores(ov, yw, n_total, group, dst)
+    return gather_scores(ov, yw, n_total, group, dst, align)
+
+
+def _comm_device(t: torch.Tensor, group=None) -> torch.Tensor:
+    """gloo moves host tensors, nccl (= RCCL) device tensors."""
+    return t.cpu() if dist.get_backend(group) == "gloo" else t
+
+
+def allgather_by_owner(overlap: torch.Tensor, yaw: torch.Tensor, owner: np.ndarray, group=None
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Every rank holds the (overlap, yaw) of the list entries it owns (`owner[i]` = rank of entry i, known to all ranks), in list
+    order; ONE all-gather of 8 B per entry (padded to the largest share) gives every rank the whole list in list order."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    owner = np.asarray(owner)
+    counts = [int((owner == r).sum()) for r in range(world)]
+    if overlap.numel() != counts[rank]:
+        raise ValueError("rank %d holds %d scores, it owns %d list entries" % (rank, overlap.numel(), counts[rank]))
+    m = max(counts) if counts else 0
+    payload = torch.zeros((m, 2), dtype=torch.int32, device=overlap.device)
+    if overlap.numel():
+        payload[:overlap.numel()] = pack_scores(overlap, yaw)
+    payload = _comm_device(payload, group)
+    bufs = [torch.empty_like(payload) for _ in range(world)]
+    dist.all_gather(bufs, payload, group=group)
+    out = torch.zeros((len(owner), 2), dtype=torch.int32, device=payload.device)
+    for r in range(world):
+        if counts[r]:
+            out[torch.from_numpy(np.nonzero(owner == r)[0]).to(out.device)] = bufs[r][:counts[r]]
+    return unpack_scores(out)
+
 
 
 def best_match(overlap: torch.Tensor, yaw: torch.Tensor, threshold: float = 0.3):
@@ -97,6 +153,32 @@ def merge_matches(records) -> "torch.Tensor":
     if best is None:
         return torch.tensor([-1, 0, 0, 0], dtype=torch.int32)
     return best[1].clone()
+
+
+def merge_matches_by_position(records) -> "torch.Tensor":
+    """Best of per-rank records whose id field is the POSITION of the candidate in the caller's reference list (shares of a list
+    that are not contiguous, `frame_owner`): largest overlap, lowest position on ties == np.argmax over the whole list
+    (demo3_lcd.py:119-120)."""
+    rec = records.reshape(-1, 4).to(torch.int32).cpu()
+    best = None
+    for r in rec:
+        if int(r[0]) < 0 or int(r[3]) == 0:
+            continue
+        v = float(r[1:2].view(torch.float32)[0])
+        if best is None or v > best[0] or (v == best[0] and int(r[0]) < int(best[1][0])):
+            best = (v, r)
+    if best is None:
+        return torch.tensor([-1, 0, 0, 0], dtype=torch.int32)
+    return best[1].clone()
+
+
+def allgather_records(record: torch.Tensor, group=None) -> torch.Tensor:
+    """(world, 4) int32: every rank's 16-byte best-match record."""
+    world = dist.get_world_size(group)
+    rec = _comm_device(record.contiguous(), group)
+    bufs = [torch.empty_like(rec) for _ in range(world)]
+    dist.all_gather(bufs, rec, group=group)
+    return torch.stack([b.cpu() for b in bufs])
 
 
 def best_match_sharded(record: torch.Tensor, group=None) -> "torch.Tensor":

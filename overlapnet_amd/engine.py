@@ -469,7 +469,9 @@ class QueryAhead:
     stream is running for the CURRENT query (a recorded sequence, or a live one whose next scan has arrived: the 1-vs-N sweep of
     `Infer.infer_multiple`, infer.py:162-203, spends 0.15 ms of its ~5.6 ms per query in a single-scan leg whose five kernels are a
     handful of workgroups deep in their own latency and leave the GPU idle).  A context owns its scratch, hence the second context;
-    features and spectra are double-buffered, so a result stays valid until the submit after the next.
+    features and spectra are double-buffered: the pair handed out by take() may be read by work enqueued on the current stream
+    up to the NEXT submit() / take() call (that call records, on the current stream, the event the slot's next overwrite waits
+    for -- whatever `wait_current` says); work enqueued later must read its own copy.
 
         qa = QueryAhead(engine, weights, model_cfg)
         qa.submit(image_0)
@@ -497,16 +499,28 @@ class QueryAhead:
             self._dc = ([torch.empty((1, engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev) for _ in range(2)]
                         if with_delta_cache and engine.has_delta_cache else None)
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]
-            self._released = [None, None]      # recorded on the consumer's stream when a slot's results are handed out again
+            self._released = [None, None]      # recorded on the consumer's stream behind the last reader of a slot's contents
         self._submitted = 0
         self._taken = 0
+        self._last = None                      # slot handed out by the latest take(), not yet released
+
+    def _release_last(self) -> None:
+        """The consumer has enqueued its readers of the slot last handed out by now (contract above): an event behind them on the
+        current stream is what the next overwrite of that slot waits for."""
+        if self._last is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.main.device))
+            self._released[self._last] = ev
+            self._last = None
 
     def submit(self, image: torch.Tensor, wait_current: bool = True) -> None:
         """Enqueue leg + spectrum of `image` (1, in_h, in_w, in_c) on the side stream; at most two queries may be in flight.
         `wait_current=False`: the image was produced on `self.stream` itself (e.g. its host-to-device copy was issued there), so the
-        side stream need not wait for the work already enqueued on the caller's stream."""
+        side stream need not wait for the work already enqueued on the caller's stream -- except for the readers of the slot it is
+        about to overwrite, which it always waits for."""
         if self._submitted - self._taken >= 2:
             raise _lib.OvnError("QueryAhead.submit: two queries are already in flight, take() one first")
+        self._release_last()
         slot = self._submitted & 1
         if self.side.leg_precision != self.main.leg_precision:       # follow the main engine's arithmetic (same bits as engine.leg)
             self.side.set_leg_precision(self.main.leg_precision)
@@ -527,24 +541,22 @@ class QueryAhead:
 
     def take(self) -> Tuple[torch.Tensor, torch.Tensor]:
         """(feature volume (1, 360, 128), spectrum) of the oldest submitted query; the CURRENT stream waits for them, the host does
-        not.  The pair stays valid until the second submit() after this call."""
+        not.  Readers of the pair must be enqueued on the current stream before the next submit() / take() call (class docstring)."""
         if self._taken >= self._submitted:
             raise _lib.OvnError("QueryAhead.take: nothing submitted")
+        self._release_last()
         slot = self._taken & 1
         cur = torch.cuda.current_stream(self.main.device)
         cur.wait_event(self._ready[slot])
-        other = slot ^ 1
-        ev = torch.cuda.Event()          # work enqueued on `cur` so far includes every reader of the OTHER slot's previous contents
-        ev.record(cur)
-        self._released[other] = ev
         self._taken += 1
         self._last = slot
+        self._last_taken = slot
         return self._fv[slot], self._spec[slot]
 
     def take_all(self):
         """take() plus the Delta cache row (None unless built with `with_delta_cache` on a head geometry that has one)."""
         fv, spec = self.take()
-        return fv, spec, (self._dc[self._last] if self._dc is not None else None)
+        return fv, spec, (self._dc[self._last_taken] if self._dc is not None else None)
 
     def close(self) -> None:
         self.stream.synchronize()

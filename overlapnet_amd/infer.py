@@ -14,6 +14,10 @@ types and error behaviour; the Keras/TensorFlow models behind it are replaced by
   * `pretrained_weightsfilename` may name a native `.npz` (keys `<layer>/kernel|bias`) besides the
     Keras HDF5 file (read by the built-in `hdf5_lite` parser);
   * `infer_best_match` (extension): `infer_multiple` + demo3's decision taken on the GPU;
+  * `config['scan_folder']` (extension key): read the RAW scans `<scan_folder>/<frame>.bin` and project them on the GPU
+    (`ovn_project`: range image + normals + intensity straight into the stacked leg input) instead of reading demo1's `.npy`
+    files -- demo1 + demo2/demo3 in one object (BASELINE configs[4]); same bits as the `.npy` route on files written by
+    `overlapnet_amd.preprocess`;
   * `self.leg` / `self.head` are the native engine, not keras.Model objects.
 """
 from __future__ import annotations
@@ -35,11 +39,13 @@ class FeatureVolumeCache(object):
   """`Infer.feature_volumes`: behaves like the reference's Python list of (1, 360, 128) arrays (infer.py:114,185), but the
   volumes live in HBM (together with their spectra) and are copied to the host one at a time when indexed."""
 
-  def __init__(self, engine, min_capacity=1024):
+  def __init__(self, engine, min_capacity=1024, with_delta_cache=True):
     """min_capacity: smallest allocation (volumes) on first use -- 1024 (580 MB with the spectra and the Delta cache rows) for the persistent cache of
     `infer_multiple`, which grows by one frame per call; the throw-away caches of `infer_one` / `infer_multiple_vs_multiple`
-    pass the number of volumes they will hold."""
+    pass the number of volumes they will hold.  with_delta_cache=False: no Delta cache rows (they pay when a cached frame meets
+    many queries; a throw-away cache prepares its pairs in the head kernels' scratch instead -- same bits)."""
     self._engine = engine
+    self._with_dc = bool(with_delta_cache) and engine.has_delta_cache
     self._fv = None        # (capacity, 360, 128) device tensor
     self._spec = None      # (capacity, 128, 368) device tensor: cached spectra for the correlation head
     self._dc = None        # (capacity, 49216) device tensor: Delta cache rows (candidate-side half of the Delta head's preparation)
@@ -56,11 +62,11 @@ class FeatureVolumeCache(object):
       dev = self._engine.device
       nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
       ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
-      nd = torch.empty((cap if self._engine.has_delta_cache else 0, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
+      nd = torch.empty((cap if self._with_dc else 0, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
       if self._n:
         nf[:self._n].copy_(self._fv[:self._n])
         ns[:self._n].copy_(self._spec[:self._n])
-        if self._engine.has_delta_cache:
+        if self._with_dc:
           nd[:self._n].copy_(self._dc[:self._n])
       self._fv, self._spec, self._dc = nf, ns, nd
     self._fv[self._n:self._n + k].copy_(fv)
@@ -68,7 +74,7 @@ class FeatureVolumeCache(object):
       self._spec[self._n:self._n + k].copy_(spec)
     else:
       self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
-    if self._engine.has_delta_cache:
+    if self._with_dc:
       if dc is not None:
         self._dc[self._n:self._n + k].copy_(dc)
       else:
@@ -86,7 +92,7 @@ class FeatureVolumeCache(object):
   @property
   def device_delta_cache(self) -> Optional[torch.Tensor]:
     """Delta cache rows of the cached volumes, or None when the head geometry has none (conv1size != 15)."""
-    if not self._engine.has_delta_cache:
+    if not self._with_dc:
       return None
     return self._dc[:self._n] if self._dc is not None else torch.empty((0, self._engine.DELTA_CACHE_ELEMS), device=self._engine.device)
 
@@ -132,13 +138,36 @@ _VALID_ORIENTATION_HEADS = ("CorrelationHead",)                # generateNet.py:
 class Infer():
   """ A class used for inferring overlap and yaw-angle between LiDAR scans (MI355X-native). """
 
-  def __init__(self, config, device: Optional[int] = None, weights: Optional[dict] = None, seed: int = 0):
+  def __init__(self, config, device: Optional[int] = None, weights: Optional[dict] = None, seed: int = 0,
+               rank: Optional[int] = None, world: Optional[int] = None, group=None):
     """ Args:
           config: dict with configuration values, usually loaded from network.yml (infer.py:26-84).
           device / weights / seed: extensions -- HIP device index, an in-memory weight dict that
           overrides `pretrained_weightsfilename`, and the seed of the Keras-default random init that
           is used when no weights are given (the reference keeps Keras' random init, infer.py:121-122).
+          rank / world / group: extension -- the 1-vs-N sweep of `infer_multiple` / `infer_best_match` sharded over `world`
+          processes (one per GPU, torch.distributed initialised by the caller).  Every rank makes the SAME calls
+          with the same arguments and gets the same results.  Frame i's feature volume / spectrum / Delta row live on rank
+          `distributed.frame_owner(i)` only (blocks of 32 consecutive frames go round the ranks), the query leg runs on every
+          rank (cheaper than a broadcast), each rank scores the references it owns and ONE all-gather of 8 B per reference (or of
+          one 16-byte best-match record per rank) merges the answer.  Same bits as the unsharded object.  `infer_one`,
+          `infer_multiple_vs_multiple` and `create_feature_volumes` run replicated on every rank.
+          config['stream_ahead'] (optional, default True): the speculative read + leg of frame i + 1 beside frame i's heads.
     """
+    self._rank, self._world, self._group = 0, 1, group
+    if world is not None and int(world) > 1:
+      import torch.distributed as dist
+      if not dist.is_initialized():
+        raise Exception('Infer(world=%d): initialise torch.distributed first (one process per GPU)' % int(world))
+      self._world = int(world)
+      self._rank = int(dist.get_rank(group) if rank is None else rank)
+      if not 0 <= self._rank < self._world or self._world != dist.get_world_size(group):
+        raise Exception('Infer: rank %d / world %d do not match the process group' % (self._rank, self._world))
+    self._n_frames = 0          # sharded mode: frames fed so far (== the next frame id)
+    self._scan_folder = config.get('scan_folder') or None
+    if self._scan_folder is not None and config['use_class_probabilities']:
+      raise Exception("config['scan_folder']: the semantic channels come from RangeNet++ .npy files, not from the raw scans")
+    self._stream_ahead = bool(config.get('stream_ahead', True))
     self.network_output_size = config['model']['leg_output_width']      # infer.py:31
     self.seq = config['infer_seqs']                                     # infer.py:32
     self.datasetpath = config['data_root_folder']                       # infer.py:34
@@ -215,7 +244,26 @@ class Infer():
     self.engine.load_weights(w, self._model_cfg)
     self._weights = w           # kept for the second context of the streaming path (_start_ahead)
     self._qa = None
-    self._ahead_fv = None       # name of the frame whose leg is running (or done) on the side stream
+    self._ahead_fv = None       # key of the frame whose leg is running (or done) on the side stream
+    self._ahead_sig = None      # (datasetpath, seq, name, (mtime_ns, size) of every cue file) the speculative read saw
+
+  def close(self) -> None:
+    """Release the second (look-ahead) context and the engine; the object cannot be used afterwards."""
+    if self._qa is not None:
+      try:
+        self._qa.close()
+      finally:
+        self._qa = None
+    if getattr(self, 'engine', None) is not None:
+      self.engine.close()
+
+  def __del__(self):
+    try:
+      if getattr(self, '_qa', None) is not None:
+        self._qa.close()
+        self._qa = None
+    except Exception:
+      pass
 
   @property
   def feature_volumes(self):
@@ -312,12 +360,41 @@ class Infer():
     except Exception:
       self._ahead = None
 
-  def _inputs_device(self, filenames: Sequence[str]) -> torch.Tensor:
+  def _scan_path(self, name: str) -> str:
+    return os.path.join(self._scan_folder, name + '.bin')
+
+  def _inputs_from_scans(self, filenames: Sequence[str], engine=None) -> torch.Tensor:
+    """(n,h,w,C) leg input from the RAW scans (gen_depth_data.py:31-32 reads them the same way): one batched `ovn_project`
+    (utils.py:59-186 on the GPU) writes depth | normals | intensity in the reference's channel order straight into the stacked
+    tensor.  `engine`: the context whose scratch the projection uses (the look-ahead passes its second context)."""
+    eng = engine or self.engine
+    pts, offs = [], [0]
+    for name in filenames:
+      f = self._scan_path(name)
+      try:
+        p = np.fromfile(f, dtype=np.float32)
+      except (IOError, OSError):
+        raise Exception('Could not read scan file %s' % f)
+      p = p.reshape((-1, 4))
+      pts.append(p)
+      offs.append(offs[-1] + p.shape[0])
+    flat = np.concatenate(pts, axis=0) if offs[-1] else np.zeros((1, 4), np.float32)
+    dev = eng.device
+    pd = torch.from_numpy(np.ascontiguousarray(flat)).to(dev, non_blocking=False)
+    od = torch.tensor(offs, dtype=torch.int64, device=dev)
+    h, w, c = self.inputShape
+    r = eng.project(pd, od, max(p.shape[0] for p in pts) if pts else 0, h, w, want=(),
+                    stacked_flags=(bool(self.use_depth), bool(self.use_normals), bool(self.use_intensity)))
+    return r["stacked"]
+
+  def _inputs_device(self, filenames: Sequence[str], engine=None) -> torch.Tensor:
     """(n,h,w,C) leg input on the device: every cue's files are read straight into a pinned staging buffer, copied asynchronously
     and interleaved by one device-side concatenation (a strided host-side interleave plus a pageable copy cost more than the leg
     itself for a single frame)."""
     n = len(filenames)
     dev = self.engine.device
+    if self._scan_folder is not None:
+      return self._inputs_from_scans(filenames, engine)
     self._ensure_stage(n)
     slot = self._stage_next
     self._stage_next ^= 1
@@ -390,10 +467,10 @@ class Infer():
     self.filenames = np.array([filename2, filename1])
 
     preprocess_data_folder = os.path.join(self.datasetpath, self.seq)
-    if not os.path.isdir(preprocess_data_folder):
+    if self._scan_folder is None and not os.path.isdir(preprocess_data_folder):
       raise Exception('Please first generate preprocessed input data.')
 
-    pair = FeatureVolumeCache(self.engine, min_capacity=2)
+    pair = FeatureVolumeCache(self.engine, min_capacity=2, with_delta_cache=False)
     pair.extend_device(self._leg_device(list(self.filenames)))
     indizes = np.zeros((1, 2), dtype=int)
     indizes[0, 0] = 0
@@ -408,24 +485,58 @@ class Infer():
     asks for frame i + 1 next (demo3_lcd.py:88-123), and its single-scan leg (0.15 ms of latency-bound kernels) would otherwise
     sit in front of its own heads with the GPU nearly idle.  Purely speculative: a missing file, or a different next request, and
     the next call computes its frame as usual."""
+    if not self._stream_ahead:
+      return
     try:
       names = [str(int(current_frame_id) + 1).zfill(6)]
     except (TypeError, ValueError):
       return
     self._drop_ahead()
-    self._readahead(names)
-    if self._ahead is None:
+    sig = self._frame_signature(names[0])     # BEFORE the read: a file rewritten during or after it no longer matches
+    if sig is None:
       return
+    if self._scan_folder is None:
+      self._readahead(names)
+      if self._ahead is None:
+        return
     try:
       if self._qa is None:
         from .engine import QueryAhead
         self._qa = QueryAhead(self.engine, self._weights, self._model_cfg, with_delta_cache=True)
       with torch.cuda.stream(self._qa.stream):
-        x = self._inputs_device(names)          # copies + interleave on the side stream (consumes the read-ahead)
+        # copies + interleave (or the projection of the raw scan, in the second context's scratch) on the side stream
+        x = self._inputs_device(names, engine=self._qa.side)
       self._qa.submit(x, wait_current=False)
       self._ahead_fv = names[0]
+      self._ahead_sig = sig
     except Exception:
       self._ahead_fv = None
+
+  def _frame_signature(self, name: str):
+    """(dataset path, sequence, frame name, (mtime_ns, size) of each cue file) -- what a speculative result is keyed by: the look-
+    ahead is adopted only if the files are still the ones it read (live preprocessing may rewrite frame i + 1 between two calls;
+    `self.seq` / `self.datasetpath` may change).  None if a file is missing."""
+    if self._scan_folder is not None:
+      try:
+        a = os.stat(self._scan_path(name))
+      except OSError:
+        return None
+      return (self._scan_folder, self.seq, name, ((a.st_mtime_ns, a.st_size),))
+    root = os.path.join(self.datasetpath, self.seq)
+    st = []
+    for sub, k, label in self._cue_files():
+      f = os.path.join(root, sub, name + '.npy')
+      try:
+        a = os.stat(f)
+      except OSError:
+        if label is not None:
+          return None
+        try:
+          a = os.stat(os.path.join(root, sub, name + '.npz'))
+        except OSError:
+          return None
+      st.append((a.st_mtime_ns, a.st_size))
+    return (self.datasetpath, self.seq, name, tuple(st))
 
   def _drop_ahead(self) -> None:
     if self._ahead_fv is not None:
@@ -435,17 +546,97 @@ class Infer():
   def _cache_frame(self, name: str) -> None:
     """Append frame `name` to the feature-volume cache on the current stream: the side stream's feature volume, spectrum and Delta
     cache row if that is the frame it was given, a fresh leg (+ spectrum + row) otherwise -- the same kernels, the same bits."""
-    if self._ahead_fv == name:
+    if self._ahead_fv == name and self._ahead_sig is not None and self._ahead_sig == self._frame_signature(name):
       self._ahead_fv = None
       fv, spec, dc = self._qa.take_all()
       self.feature_volumes.extend_device(fv, spec=spec, dc=dc)
       return
     self._drop_ahead()
+    self._ahead = None          # a stale speculative read of the staging buffers is not adopted either
     self.feature_volumes.extend_device(self._leg_device([name]))
+
+  # ---- sharded 1-vs-N sweep (extension; SURVEY.md 8e) ------------------------------------------------------------------------------
+  def _query_frame_sharded(self, current_frame_id):
+    """Leg (+ spectrum, Delta row) of the current frame on EVERY rank; the owner appends it to its local cache.  Returns the
+    query's (feature volume, spectrum) device tensors, valid for the head launches of this call."""
+    from . import distributed as D
+    fid = int(current_frame_id)
+    if fid != self._n_frames:
+      raise Exception('sharded Infer: frames must be fed in order 0, 1, 2, ... (the cache index is the frame id, infer.py:184-190); '
+                      'got frame %d, expected %d' % (fid, self._n_frames))
+    name = str(fid).zfill(6)
+    if self._ahead_fv == name and self._ahead_sig is not None and self._ahead_sig == self._frame_signature(name):
+      self._ahead_fv = None
+      fv, spec, dc = self._qa.take_all()
+    else:
+      self._drop_ahead()
+      self._ahead = None
+      fv = self._leg_device([name])
+      spec = self.engine.spectrum(fv)
+      dc = None
+    self._n_frames += 1
+    if D.frame_owner(fid, self._world) == self._rank:
+      cache = self.feature_volumes
+      cache.extend_device(fv, spec=spec, dc=dc)
+      k = len(cache) - 1
+      assert k == D.frame_slot(fid, self._world)
+      return cache.device_features[k:k + 1], cache.device_spectra[k:k + 1]
+    return fv, spec
+
+  def _local_heads_sharded(self, ref: np.ndarray, q_fv, q_spec):
+    """Heads of the references this rank owns, in list order -> (owner array, result dict or None)."""
+    from . import distributed as D
+    if len(ref) and (ref.min() < 0 or ref.max() >= self._n_frames):
+      raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(ref.max()), self._n_frames))
+    owner = D.frame_owner(ref, self._world)
+    mine = owner == self._rank
+    if not mine.any():
+      return owner, mine, None
+    cache = self.feature_volumes
+    lidx = np.ascontiguousarray(D.frame_slot(ref[mine], self._world), dtype=np.int32)
+    r = self.engine.heads(cache.device_features, q_fv, lidx=lidx, n=len(lidx), spec_l=cache.device_spectra, spec_r=q_spec,
+                          dcache_l=cache.device_delta_cache)
+    return owner, mine, r
+
+  def _infer_multiple_sharded(self, current_frame_id, reference_frame_id):
+    from . import distributed as D
+    q_fv, q_spec = self._query_frame_sharded(current_frame_id)
+    ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
+    if len(ref) == 0:
+      return None
+    owner, mine, r = self._local_heads_sharded(ref, q_fv, q_spec)
+    self._start_ahead(current_frame_id)
+    dev = self.engine.device
+    ov = r["overlap"] if r is not None else torch.empty(0, dtype=torch.float32, device=dev)
+    yw = r["yaw"] if r is not None else torch.empty(0, dtype=torch.int32, device=dev)
+    ov_all, yaw_all = D.allgather_by_owner(ov, yw, owner, self._group)
+    overlap = ov_all.cpu().numpy().reshape(-1, 1)
+    return overlap.squeeze(), yaw_all.cpu().numpy().astype(np.int64)
+
+  def _infer_best_match_sharded(self, current_frame_id, reference_frame_id, overlap_thres):
+    from . import distributed as D
+    from .engine import decode_match
+    q_fv, q_spec = self._query_frame_sharded(current_frame_id)
+    ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
+    if len(ref) == 0:
+      return None
+    owner, mine, r = self._local_heads_sharded(ref, q_fv, q_spec)
+    if r is not None:     # the record's id field carries the POSITION in the reference list: ties resolve like np.argmax over the list
+      pos = torch.from_numpy(np.nonzero(mine)[0].astype(np.int32)).to(self.engine.device)
+      rec = self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=pos)
+    else:
+      rec = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=self.engine.device)
+    self._start_ahead(current_frame_id)
+    got = decode_match(D.merge_matches_by_position(D.allgather_records(rec, self._group)))
+    if got is None:
+      return None
+    return int(ref[got[0]]), got[1], got[2]
 
   def infer_multiple(self, current_frame_id, reference_frame_id):
     """ Loop closing: current frame vs old frames (infer.py:162-203).  The current frame's feature
         volume is computed and appended (index == frame id); older ones must already be cached. """
+    if self._world > 1:
+      return self._infer_multiple_sharded(current_frame_id, reference_frame_id)
     self._cache_frame(str(current_frame_id).zfill(6))
 
     if len(reference_frame_id) > 0:
@@ -465,6 +656,8 @@ class Infer():
         (demo3_lcd.py:117-120) taken on the GPU, so only one record crosses PCIe instead of N scores.
         Returns (reference frame id, overlap, yaw) or None; caches the current frame like `infer_multiple`. """
     from .engine import decode_match
+    if self._world > 1:
+      return self._infer_best_match_sharded(current_frame_id, reference_frame_id, overlap_thres)
     self._cache_frame(str(current_frame_id).zfill(6))
     if len(reference_frame_id) == 0:
       return None

@@ -1,0 +1,112 @@
+"""Worker of tests/test_gpu_two_ranks.py: one of TWO processes that share cuda:0 (gloo rendezvous on 127.0.0.1, host tensors in the
+collectives) and run the REAL kernels on their shard.  argv: <scenario> <work dir>.  Rank 0 writes <work dir>/result.json."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from overlapnet_amd import distributed as D  # noqa: E402
+from overlapnet_amd.engine import OvnEngine, decode_match  # noqa: E402
+from tools import synthetic as S  # noqa: E402
+
+
+def engine_sweep(work):
+    """each rank runs engine.heads on its shard_bounds block of a 2,051-candidate pool and best_match on it; the
+    gather must equal the single-process sweep bit for bit, the merged decision its decision."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    e = OvnEngine(64, 900, 4, device=0)
+    e.load_weights(S.make_test_weights(4, seed=0), S.REFERENCE_MODEL_CFG)
+    N = 2051
+    g = torch.Generator(device="cuda").manual_seed(77)
+    pool = torch.relu(torch.randn((N, 360, 128), device="cuda", generator=g) + 0.1)
+    pool *= torch.rand((N, 1, 1), device="cuda", generator=g) * 1.5 + 0.5
+    q = torch.relu(torch.randn((1, 360, 128), device="cuda", generator=g) + 0.1)
+    qs = e.spectrum(q)
+    out = {}
+    for align in (D.SLOT_ALIGN, 1):
+        lo, hi = D.shard_bounds(N, world, rank, align)
+        mine = pool[lo:hi].contiguous()
+        r = e.heads(mine, q, spec_l=e.spectrum(mine), spec_r=qs, dcache_l=e.delta_cache(mine))
+        rec = e.best_match(r["overlap"], r["yaw"], 0.3, index_offset=lo)
+        got = D.gather_scores(r["overlap"], r["yaw"], N, align=align)
+        best = D.best_match_sharded(rec)
+        if rank == 0:
+            full = e.heads(pool, q, spec_l=e.spectrum(pool), spec_r=qs, dcache_l=e.delta_cache(pool))
+            f_ov, f_yaw = full["overlap"].cpu(), full["yaw"].cpu()
+            key = "aligned" if align > 1 else "unaligned"
+            out[key] = {"bounds": [lo, hi], "overlap_equal": bool(torch.equal(got[0], f_ov)), "yaw_equal": bool(torch.equal(got[1], f_yaw)),
+                        "max_abs_diff": float((got[0] - f_ov).abs().max()),
+                        "decision": list(decode_match(best) or ()), "decision_single": list(decode_match(e.best_match(full["overlap"], full["yaw"], 0.3)) or ())}
+    e.close()
+    return out
+
+
+def infer_api(work):
+    """`Infer(config, rank=, world=)` against the unsharded object on the same files: every call of a 70-frame
+    streaming run (all previous frames, gated subsets, best-match decisions), bit for bit."""
+    from overlapnet_amd.infer import Infer
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = json.load(open(os.path.join(work, "config.json")))
+    w = S.make_test_weights(4, seed=0)
+    frames = cfg.pop("_frames")
+    sh = Infer(json.loads(json.dumps(cfg)), weights=w, rank=rank, world=world)
+    ref = Infer(json.loads(json.dumps(cfg)), weights=w) if rank == 0 else None
+    rng = np.random.default_rng(5)
+    report = {"calls": 0, "mismatch": [], "local_frames": None, "best": []}
+    for i in range(frames):
+        if i % 7 == 3 and i > 4:
+            refs = sorted(rng.choice(i, size=min(i, 9), replace=False).tolist())      # a gated subset
+        elif i % 11 == 5:
+            refs = []
+        else:
+            refs = list(range(i))
+        if i % 5 == 4:
+            a = sh.infer_best_match(i, refs, 0.3)
+            if rank == 0:
+                b = ref.infer_best_match(i, refs, 0.3)
+                report["best"].append([list(a) if a else None, list(b) if b else None])
+                if a != b:
+                    report["mismatch"].append(["best", i])
+        else:
+            a = sh.infer_multiple(i, refs)
+            if rank == 0:
+                b = ref.infer_multiple(i, refs)
+                same = (a is None and b is None) or (a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                                                     and a[0].shape == b[0].shape and a[1].dtype == b[1].dtype)
+                if not same:
+                    report["mismatch"].append(["multiple", i])
+        report["calls"] += 1
+    counts = [None, None]
+    dist.all_gather_object(counts, len(sh.feature_volumes))
+    report["local_frames"] = counts
+    try:
+        sh.infer_multiple(frames + 3, [0])           # out of order: refused in sharded mode
+        report["order_error"] = False
+    except Exception as ex:
+        report["order_error"] = "order" in str(ex)
+    sh.close()
+    if ref is not None:
+        ref.close()
+    return report
+
+
+def main():
+    scenario, work = sys.argv[1], sys.argv[2]
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+    try:
+        out = {"engine_sweep": engine_sweep, "infer_api": infer_api}[scenario](work)
+        if dist.get_rank() == 0:
+            json.dump(out, open(os.path.join(work, "result.json"), "w"))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

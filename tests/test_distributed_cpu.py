@@ -139,3 +139,77 @@ def test_best_match_sharded_world2_gloo(n_total):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(2))
     assert res == {0: True, 1: True}          # every rank holds the same, correct decision
+
+
+def test_aligned_shard_bounds_and_block_cyclic_ownership():
+    """align = 32: every shard starts at a multiple of 32 (a candidate keeps its slot mod 32 -> the kernels' summation order);
+    frame ownership of a growing cache: blocks of 32 frames go round the ranks, local slots are dense and == frame id mod 32."""
+    for n in (0, 5, 31, 32, 33, 2051, 100000, 100003):
+        for world in (1, 2, 3, 8):
+            b = [D.shard_bounds(n, world, r, D.SLOT_ALIGN) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert all(lo % 32 == 0 or lo == n for lo, _ in b)
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 32 + 31 and sizes == D.shard_sizes(n, world, D.SLOT_ALIGN)
+    f = np.arange(1000)
+    for world in (1, 2, 3, 8):
+        own, slot = D.frame_owner(f, world), D.frame_slot(f, world)
+        assert np.all(slot % 32 == f % 32)
+        for r in range(world):
+            assert np.array_equal(slot[own == r], np.arange((own == r).sum()))      # frames arriving in order fill the local cache densely
+        assert D.frame_owner(77, world) == own[77] and D.frame_slot(77, world) == slot[77]
+
+
+def test_merge_matches_by_position_is_argmax_over_the_list():
+    thr = 0.3
+    # ids are positions in the reference list; the shares are interleaved, so the tie must go to the lowest POSITION, not rank
+    recs = torch.stack([_record(40, 0.5, 3, thr), _record(12, 0.5, -4, thr), _record(-1, 0, 0, thr)])
+    assert D.merge_matches_by_position(recs).tolist()[0] == 12
+    assert D.merge_matches_by_position(torch.stack([_record(4, 0.2, 1, thr), _record(9, 0.25, 6, thr)])).tolist() == [-1, 0, 0, 0]
+
+
+def _worker_owner(rank, world, port, n_list, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = np.random.default_rng(n_list + 1)
+        frames = np.sort(rng.choice(5000, size=n_list, replace=False)) if n_list else np.zeros(0, np.int64)
+        all_ov = torch.from_numpy((rng.integers(0, 40, n_list) / 40.0).astype(np.float32))
+        all_yaw = torch.from_numpy(rng.integers(-179, 181, n_list).astype(np.int32))
+        owner = D.frame_owner(frames, world) if n_list else np.zeros(0, np.int64)
+        mine = torch.from_numpy(np.nonzero(owner == rank)[0])
+        ov, yw = D.allgather_by_owner(all_ov[mine], all_yaw[mine], owner)
+        ok = torch.equal(ov, all_ov) and torch.equal(yw, all_yaw)
+        # decision: per-rank record with the list POSITION as id, merged
+        if len(mine):
+            k = int(torch.argmax(all_ov[mine]))
+            k = int((all_ov[mine] == all_ov[mine][k]).nonzero()[0])
+            rec = _record(int(mine[k]), float(all_ov[mine][k]), int(all_yaw[mine][k]), 0.3)
+        else:
+            rec = _record(-1, 0, 0, 0.3)
+        got = D.merge_matches_by_position(D.allgather_records(rec))
+        if n_list and float(all_ov.max()) > 0.3:
+            ok = ok and int(got[0]) == int(torch.argmax(all_ov))
+        else:
+            ok = ok and got.tolist() == [-1, 0, 0, 0]
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_list", [0, 1, 40, 1500])
+def test_allgather_by_owner_world2_gloo(n_list):
+    """The sharded `Infer.infer_multiple` / `infer_best_match` collectives with stand-in scores: every rank ends up with the whole
+    list in list order; the merged decision is np.argmax over the list."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_owner, args=(r, 2, port, n_list, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(2))
+    assert res == {0: True, 1: True}

@@ -220,3 +220,143 @@ def test_streaming_lookahead_changes_nothing(tmp_path, fixture_npz):
         assert (ra is None and rb is None) or (np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1]))
     got = inf.infer_best_match(3, [0, 1, 2], overlap_thres=0.0)      # frame 3 comes from the side stream here too
     assert got == ref.infer_best_match(3, [0, 1, 2], overlap_thres=0.0)
+
+
+def test_lookahead_is_dropped_when_the_next_frame_is_rewritten(tmp_path, fixture_npz):
+    """VERDICT r3 item 9 / ADVICE r3: the speculative leg of frame i + 1 is keyed by (dataset path, sequence, name, mtime + size of
+    every cue file).  A frame rewritten between the two calls (live preprocessing), a changed `seq`, or `stream_ahead: False` must give
+    the features of the files as they are when the frame is asked for."""
+    import time
+    from overlapnet_amd.infer import Infer
+    root = tmp_path / "data"
+    _write_sequence(str(root), fixture_npz, 4)
+    w = S.make_test_weights(4, seed=0)
+    inf = Infer(_config(root), weights=w)
+    inf.infer_multiple(0, [])
+    inf.infer_multiple(1, [0])
+    assert inf._ahead_fv == "000002"                       # frame 2's leg ran on the side stream, from the OLD files
+    old = np.load(root / "07" / "depth" / "000002.npy")
+    new = np.roll(old, 111, axis=1)
+    time.sleep(0.01)
+    np.save(root / "07" / "depth" / "000002.npy", new)     # same size, new mtime, other content
+    np.save(root / "07" / "normal" / "000002.npy", np.roll(np.load(root / "07" / "normal" / "000002.npy"), 111, axis=1))
+    got = inf.infer_multiple(2, [0, 1])
+    ref = Infer(dict(_config(root), stream_ahead=False), weights=w)
+    for i in range(3):
+        want = ref.infer_multiple(i, list(range(i)))
+    assert ref._qa is None and ref._ahead_fv is None       # opt-out: no second context was ever built
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert torch.equal(inf.feature_volumes.device_features, ref.feature_volumes.device_features)
+    # the look-ahead itself still works afterwards (frame 3 untouched)
+    assert inf._ahead_fv == "000003"
+    a, b = inf.infer_multiple(3, [0, 1, 2]), ref.infer_multiple(3, [0, 1, 2])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    inf.close()
+    ref.close()
+
+
+def test_infer_from_raw_scans(tmp_path, fixture_npz):
+    """`config['scan_folder']` (VERDICT r3 "missing" 4, BASELINE configs[4]): `Infer` reads the raw .bin scans and projects them on the
+    GPU -- demo1 + demo2/demo3 in one object.  Same bits as the .npy route on the files demo1's drivers write from the same scans,
+    look-ahead included, and within tolerance of the fp64 oracle that starts from the raw clouds (own projection + normals)."""
+    from overlapnet_amd import preprocess as P
+    from overlapnet_amd.infer import Infer
+    scans = tmp_path / "scans"
+    os.makedirs(scans)
+    n = 5
+    clouds = [S.transformed_cloud(fixture_npz, i) for i in range(n)]
+    for i, c in enumerate(clouds):
+        c.tofile(scans / ("%06d.bin" % i))
+    dst = tmp_path / "data" / "07"
+    os.makedirs(dst)
+    P.gen_depth_data(str(scans), str(dst))
+    P.gen_normal_data(str(scans), str(dst))
+    w = S.make_test_weights(4, seed=0)
+    a = Infer(_config(tmp_path / "data", scan_folder=str(scans)), weights=w)
+    b = Infer(_config(tmp_path / "data"), weights=w)
+    for i in range(n):
+        ra, rb = a.infer_multiple(i, list(range(i))), b.infer_multiple(i, list(range(i)))
+        assert (ra is None and rb is None) or (np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1], rb[1])), i
+    assert torch.equal(a.feature_volumes.device_features, b.feature_volumes.device_features)
+    assert a._qa is not None                                              # frames 2.. came from the look-ahead's projection + leg
+    oa, ya = a.infer_one(str(scans / "000001.bin"), str(scans / "000003.bin"))
+    ob, yb = b.infer_one(str(scans / "000001.bin"), str(scans / "000003.bin"))
+    assert np.array_equal(oa, ob) and np.array_equal(ya, yb)
+    # oracle from the raw clouds: l = frame 3 (second argument), r = frame 1 (infer.py:140,150-152)
+    imgs = []
+    for i in (3, 1):
+        rng, vtx, _, _ = O.range_projection(clouds[i])
+        imgs.append(S.stack(rng, O.gen_normal_map(rng, vtx), None, (True, True, False)))
+    o_ov, o_yaw, _, _, _ = O.infer_pairs(np.stack(imgs), np.array([[0, 1]]), w, S.REFERENCE_MODEL_CFG, np.float64)
+    assert abs(float(oa[0]) - float(o_ov[0])) <= 1e-4 and int(ya[0]) == int(o_yaw[0])
+    with pytest.raises(Exception, match="Could not read scan file"):
+        a.infer_multiple_vs_multiple(["missing.bin"], [0], [0])
+    a.close()
+    b.close()
+
+
+def test_reference_demos_replayed_on_the_drop_in(tmp_path, fixture_npz):
+    """VERDICT r3 "missing" 5: tests/golden/demo_transcript.json is what the reference's OWN demo2_infer.py / demo3_lcd.py (imported
+    unmodified, a recorder in place of `infer`) do with the `Infer` object: constructor config, every call with argument values and
+    types, every attribute read.  The drop-in must take exactly those calls and return objects the scripts' next lines work on
+    (demo2_infer.py:19-30,45; demo3_lcd.py:28,85-123)."""
+    import json
+    from overlapnet_amd.infer import Infer
+    t = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_transcript.json")))
+    w = S.make_test_weights(4, seed=0)
+    data = tmp_path / "data"
+
+    def write(seq, n):
+        for sub in ("depth", "normal"):
+            os.makedirs(data / seq / sub, exist_ok=True)
+        for i in range(n):
+            s, shift = i % 2, (37 * i) % 900
+            np.save(data / seq / "depth" / ("%06d.npy" % i), np.roll(fixture_npz["range_%d" % s], shift, axis=1))
+            np.save(data / seq / "normal" / ("%06d.npy" % i), np.roll(fixture_npz["normal_%d" % s], shift, axis=1))
+
+    # ---- demo2 ----
+    ev = t["demo2"]
+    assert [e["event"] for e in ev] == ["Infer", "infer_one", "getattr", "getattr", "getattr"]
+    cfg = ev[0]["config"]
+    assert cfg["data_root_folder"] == "data/" and cfg["pretrained_weightsfilename"] == "data/model_geo.weight"
+    cfg["data_root_folder"] = str(data) + "/"
+    cfg["pretrained_weightsfilename"] = ""            # the authors' weight file is not in the tree (README.md:120): seeded weights
+    write(cfg["infer_seqs"], 2)
+    infer = Infer(cfg, weights=w)
+    overlap, yaw = infer.infer_one(*ev[1]["args"])    # ('data/scans/000001.bin', 'data/scans/000000.bin'): only the names are used
+    assert [e["name"] for e in ev[2:]] == ["datasetpath", "seq", "filenames"]
+    folder = os.path.join(infer.datasetpath, infer.seq, "depth")                          # demo2_infer.py:25
+    depth_data = [np.load(os.path.join(folder, filename + ".npy")) for filename in infer.filenames]   # :27-29
+    assert len(depth_data) == 2 and list(infer.filenames) == ["000000", "000001"]
+    title = "Overlap: " + str(overlap) + "  Yaw: " + str(yaw)                              # :45
+    assert overlap.shape == (1,) and overlap.dtype == np.float32 and yaw.shape == (1,) and title.startswith("Overlap: [0.")
+    infer.close()
+
+    # ---- demo3: every infer_multiple call of a 259-frame run, in order, with the recorded argument types ----
+    ev = t["demo3"]
+    assert ev[0]["event"] == "Infer"
+    cfg = ev[0]["config"]
+    cfg["data_root_folder"] = str(data) + "/"
+    cfg["pretrained_weightsfilename"] = ""
+    calls = [e for e in ev if e["event"] == "infer_multiple"]
+    assert len(calls) == t["demo3_frames"] == 259
+    write(cfg["infer_seqs"], len(calls))
+    infer = Infer(cfg, weights=w)
+    checked = closures = 0
+    for c in calls:
+        assert c["cur_type"] == "int"
+        refs = np.asarray(c["refs"], dtype=np.int64) if c["refs_type"].startswith("ndarray") else list(c["refs"])
+        r = infer.infer_multiple(c["cur"], refs)
+        if len(refs) == 0:
+            assert r is None                                                               # demo3_lcd.py:89,122
+            continue
+        overlaps, _ = r                                                                    # :118
+        assert overlaps.dtype == np.float32 and overlaps.shape == ((len(refs),) if len(refs) > 1 else ())
+        assert _.shape == (len(refs),) and _.dtype == np.int64
+        if np.max(overlaps) > 0.3:                                                         # :119-120
+            k = refs[np.argmax(overlaps)]
+            assert k in refs
+            closures += 1
+        checked += 1
+    assert checked == 83 and len(infer.feature_volumes) == 259
+    infer.close()

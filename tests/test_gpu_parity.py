@@ -421,7 +421,8 @@ def test_projection_angles_have_numpys_float32_bits(engines, fixture_npz):
         o_pitch = B.svml_arcsin(zz[keep] / depth[keep])
         assert np.array_equal(yaw[keep].view(np.uint32), o_yaw.view(np.uint32))
         assert np.array_equal(pitch[keep].view(np.uint32), o_pitch.view(np.uint32))
-        assert (np.abs(zz[keep] / depth[keep]) >= 0.5).sum() > 100
+        if cloud is rnd:
+            assert (np.abs(zz[keep] / depth[keep]) >= 0.5).sum() > 100000      # both arcsin branches
 
 
 def test_projection_batch_ragged_and_edge_cases(engines, fixture_npz):
@@ -871,6 +872,21 @@ def test_100k_candidate_sweep_properties(engines):
     ov = r["overlap"].cpu().numpy()
     k = int(np.argmax(ov))
     assert decode_match(rec) == (k, float(ov[k]), int(yaw[k]))
+    # 16 pairs sampled over the whole pool against the fp64 oracle: overlap within 1e-4, exact yaw bin
+    w = S.make_test_weights(4, seed=0)
+    sel = np.sort(np.random.default_rng(11).choice(N, 16, replace=False))
+    sel[0], sel[-1] = 1024, N - 1                                                    # first pair of the second chunk, last pair
+    fv64 = cands[torch.from_numpy(sel).cuda()].cpu().numpy().reshape(16, 1, 360, 128).astype(np.float64)
+    q64 = np.repeat(q.cpu().numpy().reshape(1, 1, 360, 128).astype(np.float64), 16, axis=0)
+    o_ov, o_yaw, o_lg, _ = O.heads_forward(fv64, q64, w)
+    assert np.max(np.abs(ov[sel] - o_ov)) <= 1e-4 and np.array_equal(yaw[sel], o_yaw)
+    assert np.max(np.abs(lg.cpu().numpy()[sel] - o_lg) / (1 + np.abs(o_lg))) <= 1e-3
+    # the same sweep with the candidates' Delta cache rows (what Infer and bench.py run; 19.7 GB more): same bits for all 100 k pairs,
+    # no index list, 98 chunks -- the cache row of candidate p must be row p in every chunk
+    dc = e.delta_cache(cands)
+    r2 = e.heads(cands, q, spec_l=spec, spec_r=qspec, want_logit=True, dcache_l=dc)
+    torch.cuda.synchronize()
+    assert torch.equal(r2["logit"], r["logit"]) and torch.equal(r2["overlap"], r["overlap"]) and torch.equal(r2["yaw"], r["yaw"])
 
 
 def test_head_results_do_not_depend_on_the_launch_structure(engines):
@@ -896,8 +912,8 @@ def test_head_results_do_not_depend_on_the_launch_structure(engines):
         assert torch.equal(sep["yaw"], ref["yaw"]) and torch.equal(sep["corr"], ref["corr"])
         idx = torch.from_numpy(rng.permutation(n).astype(np.int32)).cuda()
         ref_idx = e.heads(fv, q, lidx=idx, spec_l=spec, spec_r=qspec, want_logit=True)
-        assert torch.equal(ref_idx["logit"], ref["logit"][idx.long()]) or \
-            torch.allclose(ref_idx["logit"], ref["logit"][idx.long()], rtol=2e-5, atol=2e-5)   # (K-walk rotation follows the position)
+        # the K-walk rotation follows the candidate's SLOT in the pool, not its place in the list: a permuted list gives the same bits
+        assert torch.equal(ref_idx["logit"], ref["logit"][idx.long()]) and torch.equal(ref_idx["yaw"], ref["yaw"][idx.long()])
         for cfg in ((1024, 256, 1, True), (1024, 256, 2, True), (1024, 100, 2, False), (300, 64, 2, True), (128, 0, 1, True),
                     (256, 96, 2, True)):
             e.set_head_pipeline(*cfg)
@@ -1142,6 +1158,20 @@ def test_query_ahead_soak_under_a_full_head_sweep(engines, fixture_images):
         torch.cuda.synchronize()
         for k, got in enumerate(results):
             bad += int(not all(torch.equal(a, b) for a, b in zip(got, want[k % 8])))
+        # the same loop with wait_current=False (images resident, nothing on the caller's stream produces them): the heads of query
+        # k - 1 read the slot that submit(k + 1) overwrites straight out of the helper's buffers -- the side stream must still wait
+        # for THEM (the release event used to be recorded before those heads were enqueued)
+        qa.submit(queries[0], wait_current=False)
+        results = []
+        for k in range(n):
+            if k + 1 < n:
+                qa.submit(queries[(k + 1) % 8], wait_current=False)
+            fv, sp = qa.take()
+            r = e.heads(cands, fv, spec_l=cspec, spec_r=sp, dcache_l=cdc)
+            results.append((r["overlap"], r["yaw"]))
+        torch.cuda.synchronize()
+        for k, got in enumerate(results):
+            bad += int(not all(torch.equal(a, b) for a, b in zip(got, want[k % 8][2:])))
     finally:
         qa.close()
     assert bad == 0

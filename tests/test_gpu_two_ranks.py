@@ -1,0 +1,64 @@
+"""GPU: two processes run the REAL kernels on their shards of one sweep (both on cuda:0, gloo rendezvous, host tensors in the
+collectives -- the box has one GPU; on a multi-GPU node the same code runs one rank per GPU over RCCL) and must reproduce the
+single-process results bit for bit: engine level (contiguous aligned blocks + one gather / one 16-byte record per rank) and through
+the drop-in `Infer(config, rank=, world=)` (block-cyclic ownership of a growing cache).  SURVEY.md 8e; reference API: infer.py:162-203."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run_two(scenario, work, timeout=600):
+    port = 29700 + os.getpid() % 200
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), scenario, str(work)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=timeout)[0])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+    return json.load(open(os.path.join(work, "result.json")))
+
+
+def test_two_ranks_engine_sweep_equals_the_single_process_sweep(tmp_path):
+    r = _run_two("engine_sweep", tmp_path)
+    a = r["aligned"]
+    assert a["bounds"][0] == 0 and a["bounds"][1] % 32 == 0
+    assert a["overlap_equal"] and a["yaw_equal"], a                  # shards that start at a multiple of 32: same bits
+    assert a["decision"] == a["decision_single"] and len(a["decision"]) == 3
+    u = r["unaligned"]                                                # 1026 | 1025: rank 1 starts at slot 1026 = 2 mod 32
+    assert u["yaw_equal"] and u["max_abs_diff"] <= 2e-6 and u["decision"][0] == u["decision_single"][0]
+
+
+def test_sharded_infer_equals_the_unsharded_object(tmp_path, fixture_npz):
+    from tools import synthetic as S
+    frames = 70
+    seq = tmp_path / "data" / "07"
+    for sub in ("depth", "normal"):
+        os.makedirs(seq / sub)
+    for i in range(frames):
+        s, shift = i % 2, (37 * i) % 900
+        np.save(seq / "depth" / ("%06d.npy" % i), np.roll(fixture_npz["range_%d" % s], shift, axis=1))
+        np.save(seq / "normal" / ("%06d.npy" % i), np.roll(fixture_npz["normal_%d" % s], shift, axis=1))
+    cfg = {"model": dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900]), "infer_seqs": "07", "data_root_folder": str(tmp_path / "data"),
+           "use_depth": True, "use_normals": True, "use_class_probabilities": False, "use_class_probabilities_pca": False,
+           "use_intensity": False, "batch_size": 16, "pretrained_weightsfilename": "", "_frames": frames}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    r = _run_two("infer_api", tmp_path)
+    assert r["calls"] == frames and r["mismatch"] == [], r
+    assert r["local_frames"] == [38, 32]                              # frames 0-31 and 64-69 on rank 0, 32-63 on rank 1
+    assert r["order_error"] is True
+    assert len(r["best"]) == frames // 5 and any(b[0] is not None for b in r["best"])

@@ -189,3 +189,9 @@ def transformed_cloud(fixture: Dict[str, np.ndarray], i: int) -> np.ndarray:
     q[:, 1] = (y + t[1]).astype(np.float32)
     q[:, 2] = (z + t[2]).astype(np.float32)
     return q
+
+
+def fullstack_cloud(fixture: Dict[str, np.ndarray], i: int) -> np.ndarray:
+    """Raw cloud i of bench.py's `fullstack` step (BASELINE configs[4] emulated): shipped scan (i mod 2) rotated about
+    z by (37 i mod 900) image columns.  Clouds 0-11 are clouds 0-11 of the preprocessing parity set (`transformed_cloud`)."""
+    return z_rotated(fixture["points_%d" % (i % 2)], (37 * i) % 900)
