@@ -45,12 +45,16 @@ class FeatureVolumeCache(object):
     pass the number of volumes they will hold.  with_delta_cache=False: no Delta cache rows (they pay when a cached frame meets
     many queries; a throw-away cache prepares its pairs in the head kernels' scratch instead -- same bits)."""
     self._engine = engine
-    self._with_dc = bool(with_delta_cache) and engine.has_delta_cache
+    self._want_dc = bool(with_delta_cache)
     self._fv = None        # (capacity, 360, 128) device tensor
     self._spec = None      # (capacity, 128, 368) device tensor: cached spectra for the correlation head
     self._dc = None        # (capacity, 49216) device tensor: Delta cache rows (candidate-side half of the Delta head's preparation)
     self._n = 0
     self._min_capacity = max(1, int(min_capacity))
+
+  @property
+  def _with_dc(self) -> bool:      # (the engine learns its head geometry when the weights are loaded, after this object is built)
+    return self._want_dc and self._engine.has_delta_cache
 
   # -- device side ---------------------------------------------------------------------------------
   def extend_device(self, fv: torch.Tensor, spec: Optional[torch.Tensor] = None, dc: Optional[torch.Tensor] = None) -> None:

@@ -297,8 +297,10 @@ def test_one_vs_n_equals_indexed_pairs_and_is_deterministic(engines):
     a = e.heads(cands, query, want_logit=True)
     b = e.heads(cands, query, want_logit=True)
     assert torch.equal(a["logit"], b["logit"]) and torch.equal(a["yaw"], b["yaw"])
-    allf = torch.cat([query, cands])
-    c = e.heads(allf, allf, lidx=np.arange(1, n + 1), ridx=np.zeros(n, np.int64), want_logit=True)
+    # (the query goes BEHIND the candidates: a candidate's slot in the left pool -- which the f16x3 kernel's summation order
+    # follows -- is then the same in both forms)
+    allf = torch.cat([cands, query])
+    c = e.heads(allf, allf, lidx=np.arange(n), ridx=np.full(n, n, np.int64), want_logit=True)
     assert torch.equal(a["logit"], c["logit"]) and torch.equal(a["yaw"], c["yaw"]) and torch.equal(a["overlap"], c["overlap"])
     # periodic inputs -> periodic outputs.  The f16x3 Delta kernel rotates its K walk with the workgroup index (L2
     # locality), so the same pair at another batch position sees its rounding errors summed in another order: ~1e-6 on
