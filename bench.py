@@ -272,7 +272,8 @@ def main():
     if strong and args.mode != "warm":
         raise SystemExit("--pool-total (one pool sharded over the ranks) is a warm sweep; use --pool-total 0 with --mode %s" % args.mode)
     if strong:
-        lo, hi = D.shard_bounds(pool_total, world, rank)
+        # blocks that start at a multiple of 32: a candidate keeps its pool slot modulo 32 -> the bits of the unsharded sweep
+        lo, hi = D.shard_bounds(pool_total, world, rank, D.SLOT_ALIGN)
         P = hi - lo
         n_total = pool_total
     else:
@@ -333,7 +334,7 @@ def main():
 
     def finish(r):
         if use_dist:
-            return D.gather_scores(r["overlap"], r["yaw"], n_total)
+            return D.gather_scores(r["overlap"], r["yaw"], n_total, align=D.SLOT_ALIGN if strong else 1)
         return r["overlap"], r["yaw"]
 
     def step_warm_serial():

@@ -737,7 +737,9 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 // (tile of 192 (jb, ib) rows, k-step major; K order of W2p: o' = 4 (o & 15) + (o >> 4)), 16 bytes per lane and accumulator row.
 // ABL (timing-only, -DOVN_ABLATE builds): 1 no o1 stores, 2 no W1 DMA, 4 no chunk barrier, 8 no L DMA / slice reads, 16 no R DMA,
 // 64 W1 DMA always from chunk 0 (cache-resident source), 128 o1 stores of every pair into 256 pairs' rows (cache-resident destination)
-template <int SPC, int ABL = 0>
+// JBP (column groups per pass): 2 for sweeps; 1 for a handful of pairs (24 half-passes per pair = 24 workgroups: twice the
+// parallelism for the single-pair latency of demo2 / gated demo3 queries; same per-accumulator order, same bits).
+template <int SPC, int ABL = 0, int JBP = 2>
 __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __restrict__ desc,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
                                                              float* __restrict__ o1raw, int rot, int nsplit, int pair0,
@@ -784,9 +786,9 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
       glds16(w1bytes + (size_t)(CH) * CHB + (q * 512 + tid) * 16, wst + (BUF) * CHB + (q * 512 + wave * 64) * 16);
 #define OVN_DMA_R(PASS, BUF)                                                                     \
   {                                                                                              \
-    const unsigned* rsrc = Rw + (size_t)(PASS) * R_PASS_WORDS;                                    \
-    glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);                    \
-    if (wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
+    const unsigned* rsrc = Rw + (size_t)(PASS) * (JBP * S * FC);                                  \
+    glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);  /* JBP 1: the group's 1920 words + 128 of what follows, never read */ \
+    if (JBP == 2 && wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
   }
 
   // rotation of the K walk by the CANDIDATE's slot in the left pool (its index-list entry, or its position in the pool when the
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   // of a pool whose first slot is a multiple of 32 (overlapnet_amd.distributed) reproduces the bits of the unsharded sweep
   const int slot = lidx ? lidx[pair] : pair0 + pair;
   const int s0 = rot ? ((slot >> 3) & 3) : 0;
-  const int p_begin = part * (G / 2) / nsplit, p_end = (part + 1) * (G / 2) / nsplit;
+  const int p_begin = part * (G / JBP) / nsplit, p_end = (part + 1) * (G / JBP) / nsplit;
   int cur = 0, rcur = 0;
   int chunk = CPS * s0;
   OVN_DMA_W(chunk, 0)
@@ -805,9 +807,9 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 
   u32x4 la[3][2];   // this lane's words of the current L slice
   for (int pass = p_begin; pass < p_end; ++pass) {
-    f32x4 acc[2][3][4];
+    f32x4 acc[JBP][3][4];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < JBP; ++j)
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -839,8 +841,10 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
     const unsigned* rrow = rsl + (c5 * SPC + (H)) * 32;                                            \
     rw[SET][0] = *reinterpret_cast<const u32x4*>(rrow);                                            \
     rw[SET][1] = *reinterpret_cast<const u32x4*>(rrow + 4);                                        \
-    rw[SET][2] = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32);                               \
-    rw[SET][3] = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32 + 4);                           \
+    if (JBP == 2) {                                                                                \
+      rw[SET][2] = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32);                             \
+      rw[SET][3] = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32 + 4);                         \
+    }                                                                                              \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                             \
       bh[SET][nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);       \
       bl[SET][nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);       \
@@ -860,13 +864,15 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
             for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[h & 1][nt], acc[0][t][nt], 0, 0, 0);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[h & 1][nt], acc[0][t][nt], 0, 0, 0);
-            make_a(la[t][0], la[t][1], rw[h & 1][2], rw[h & 1][3], ah, al);
+            if constexpr (JBP == 2) {
+              make_a(la[t][0], la[t][1], rw[h & 1][2], rw[h & 1][3], ah, al);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[h & 1][nt], acc[1][t][nt], 0, 0, 0);
+              for (int nt = 0; nt < 4; ++nt) acc[JBP - 1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[h & 1][nt], acc[JBP - 1][t][nt], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[h & 1][nt], acc[1][t][nt], 0, 0, 0);
+              for (int nt = 0; nt < 4; ++nt) acc[JBP - 1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[h & 1][nt], acc[JBP - 1][t][nt], 0, 0, 0);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[h & 1][nt], acc[1][t][nt], 0, 0, 0);
+              for (int nt = 0; nt < 4; ++nt) acc[JBP - 1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[h & 1][nt], acc[JBP - 1][t][nt], 0, 0, 0);
+            }
           }
         }
 #undef OVN_READ_FRAGS
@@ -879,8 +885,8 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
     // [row = (jb % 8) 24 + ib][o' & 31], o' = 4 lrow + nt: 16 bytes per lane, 128-byte segments, 3 KB runs per (ks, jb).  The stores
     // drain behind the next pass's first chunk.
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int jb = 2 * pass + j;
+    for (int j = 0; j < JBP; ++j) {
+      const int jb = JBP * pass + j;
       float* obase = o1raw + ((size_t)((ABL & 128) ? (pair & 15) : pair) * 3 + (jb >> 3)) * (C2_TILE_ROWS * K2) +
                      ((jb & 7) * G) * 32 + (lrow >> 3) * (C2_TILE_ROWS * 32) + 4 * (lrow & 7);
 #pragma unroll
@@ -912,31 +918,40 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 // (in-order return) never waits for the younger A loads.  Plain loads only: next to an LDS-DMA the compiler drains vmcnt(0)
 // at every barrier, which cuts the prefetch distance to one step (measured 0.60 ms; one step = the loaded HBM latency, ~3 us).
 // Epilogue: acc / (s1r sw2) + TT[ib] + AA[jb] + b2, ReLU, per-pair maximum.
+// Template: MT m-tiles per wave (workgroup = 64 MT rows), A rows ASLOTS - 1 k-steps ahead, W2 slabs WSETS k-steps ahead in registers.
+// <3, 3, 1> is the sweep kernel described above (its latency cover is other workgroups: two per CU, 768+ per launch).
+// <1, 6, 3> serves a handful of pairs (9 workgroups per pair, acc 32 registers): with nothing else on the CU, a step costs
+// the memory round trip of the operands it waits for, so they travel 5 (A) and 3 (W2) steps ahead -- 44 -> ~17 us for one pair
+// (the single-pair latency of demo2 / gated demo3 queries).  Same per-accumulator order (k-step, hi hi / lo hi / hi lo): same bits.
+template <int MT, int ASLOTS, int WSETS>
 __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __restrict__ o1raw, const _Float16* __restrict__ w2p,
                                                                          const DeltaDesc* __restrict__ desc, const f32x4* __restrict__ scales,
                                                                          float* __restrict__ o2, unsigned* __restrict__ o2max, float one) {
   __shared__ __attribute__((aligned(16))) unsigned char wb[2][16384];
   constexpr int NKS = K2 / 32;   // 30
+  constexpr int WG_ROWS = 64 * MT;
+  static_assert(C2_TILE_ROWS % WG_ROWS == 0 && 6 % ASLOTS == 0 && 6 % WSETS == 0 && NKS % 6 == 0 && ASLOTS >= 2, "bad c_conv2 tiling");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane & 15, g = lane >> 4;
-  constexpr int MT = 3;
-  const int row0 = blockIdx.x * C2_TILE_ROWS + 16 * MT * wave;   // global row (pair 576 + jb 24 + ib) of this wave's first m-tile
-  // o1raw[tile = blockIdx][ks][row in tile][32]: one k-step of the tile is 24 KB contiguous, a wave's m-tile 2 KB of it
-  const float* abase = o1raw + (size_t)blockIdx.x * (C2_TILE_ROWS * K2) + (16 * MT * wave + lrow) * 32 + 8 * g;
+  const int wg_row0 = blockIdx.x * WG_ROWS;                      // global row (pair 576 + jb 24 + ib) of the workgroup's first row
+  const int row0 = wg_row0 + 16 * MT * wave;                     // ... of this wave's first m-tile
+  // o1raw[tile of 192 rows][ks][row in tile][32]: one k-step of the tile is 24 KB contiguous, a wave's m-tile 2 KB of it
+  const int tile = wg_row0 / C2_TILE_ROWS, in_tile = wg_row0 - tile * C2_TILE_ROWS;
+  const float* abase = o1raw + (size_t)tile * (C2_TILE_ROWS * K2) + (in_tile + 16 * MT * wave + lrow) * 32 + 8 * g;
   const unsigned char* w2bytes = reinterpret_cast<const unsigned char*>(w2p) + tid * 16;
 
-  f32x4 araw[3][MT][2];   // [k-step mod 3][m-tile][half]
-  f32x4 wr[4];
+  f32x4 araw[ASLOTS][MT][2];   // [k-step mod ASLOTS][m-tile][half]
+  f32x4 wr[WSETS][4];          // [k-step mod WSETS]
 #define OVN_LOAD_A(SLOT, KS)                                                                 \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                        \
     araw[SLOT][mt][0] = *reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512);       \
     araw[SLOT][mt][1] = *reinterpret_cast<const f32x4*>(abase + (KS) * (C2_TILE_ROWS * 32) + mt * 512 + 4);   \
   }
-#define OVN_LOAD_W(KS) \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) wr[q] = *reinterpret_cast<const f32x4*>(w2bytes + (size_t)(KS) * 16384 + q * 4096);
-#define OVN_STORE_W(BUF) \
-  _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&wb[BUF][q * 4096 + tid * 16]) = wr[q];
+#define OVN_LOAD_W(SET, KS) \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) wr[SET][q] = *reinterpret_cast<const f32x4*>(w2bytes + (size_t)(KS) * 16384 + q * 4096);
+#define OVN_STORE_W(SET, BUF) \
+  _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&wb[BUF][q * 4096 + tid * 16]) = wr[SET][q];
 
   f32x4 acc[MT][8];
 #pragma unroll
@@ -944,28 +959,32 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  OVN_LOAD_W(0)
-  OVN_LOAD_A(0, 0)
-  OVN_LOAD_A(1, 1)
-  OVN_STORE_W(0)
+  // prologue: W2 slabs of steps 0 .. WSETS - 1 (each ahead of the A rows requested after it), A rows of steps 0 .. ASLOTS - 2
+#pragma unroll
+  for (int k = 0; k < WSETS; ++k) OVN_LOAD_W(k, k)
+#pragma unroll
+  for (int k = 0; k < ASLOTS - 1; ++k) OVN_LOAD_A(k, k)
+  OVN_STORE_W(0, 0)
   __syncthreads();
 
-#define OVN_C2_STEP(SLOT, KS)                                                                                     \
+  // J = k-step modulo 6 (compile time): register slots and the LDS buffer follow from it
+#define OVN_C2_STEP(J, KS)                                                                                        \
   {                                                                                                               \
-    if ((KS) + 1 < NKS) OVN_LOAD_W((KS) + 1)                                                                      \
-    if ((KS) + 2 < NKS) OVN_LOAD_A(((SLOT) + 2) % 3, (KS) + 2)                                                    \
+    /* set J % WSETS held step KS's slab, stored to LDS at the end of the previous step: free for step KS + WSETS */ \
+    if ((KS) + WSETS < NKS) OVN_LOAD_W((J) % WSETS, (KS) + WSETS)                                                 \
+    if ((KS) + ASLOTS - 1 < NKS) OVN_LOAD_A(((J) + ASLOTS - 1) % ASLOTS, (KS) + ASLOTS - 1)                       \
     __builtin_amdgcn_sched_barrier(0);   /* the scheduler otherwise sinks the loads next to their first use */      \
     f16x8 ah[MT], al[MT];                                                                                         \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                           \
       unsigned h0, h1, h2, h3, l0, l1, l2, l3;                                                                    \
-      split_pair(araw[SLOT][mt][0][0], araw[SLOT][mt][0][1], one, h0, l0);                                        \
-      split_pair(araw[SLOT][mt][0][2], araw[SLOT][mt][0][3], one, h1, l1);                                        \
-      split_pair(araw[SLOT][mt][1][0], araw[SLOT][mt][1][1], one, h2, l2);                                        \
-      split_pair(araw[SLOT][mt][1][2], araw[SLOT][mt][1][3], one, h3, l3);                                        \
+      split_pair(araw[(J) % ASLOTS][mt][0][0], araw[(J) % ASLOTS][mt][0][1], one, h0, l0);                        \
+      split_pair(araw[(J) % ASLOTS][mt][0][2], araw[(J) % ASLOTS][mt][0][3], one, h1, l1);                        \
+      split_pair(araw[(J) % ASLOTS][mt][1][0], araw[(J) % ASLOTS][mt][1][1], one, h2, l2);                        \
+      split_pair(araw[(J) % ASLOTS][mt][1][2], araw[(J) % ASLOTS][mt][1][3], one, h3, l3);                        \
       ah[mt] = __builtin_bit_cast(f16x8, (u32x4){h0, h1, h2, h3});                                                \
       al[mt] = __builtin_bit_cast(f16x8, (u32x4){l0, l1, l2, l3});                                                \
     }                                                                                                             \
-    const unsigned char* wcur = &wb[(KS) & 1][lane * 16];                                                         \
+    const unsigned char* wcur = &wb[(J) & 1][lane * 16];                                                          \
     _Pragma("unroll") for (int nt = 0; nt < 8; ++nt) {                                                            \
       const f16x8 bh = *reinterpret_cast<const f16x8*>(wcur + (nt * 2) * 1024);                                   \
       const f16x8 bl = *reinterpret_cast<const f16x8*>(wcur + (nt * 2 + 1) * 1024);                               \
@@ -976,7 +995,7 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
       _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                           \
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);                 \
     }                                                                                                             \
-    if ((KS) + 1 < NKS) OVN_STORE_W(((KS) + 1) & 1)                                                               \
+    if ((KS) + 1 < NKS) OVN_STORE_W(((J) + 1) % WSETS, ((J) + 1) & 1)                                             \
     __syncthreads();                                                                                              \
   }
 #pragma unroll 1
@@ -984,9 +1003,9 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
     OVN_C2_STEP(0, ks)
     OVN_C2_STEP(1, ks + 1)
     OVN_C2_STEP(2, ks + 2)
-    OVN_C2_STEP(0, ks + 3)
-    OVN_C2_STEP(1, ks + 4)
-    OVN_C2_STEP(2, ks + 5)
+    OVN_C2_STEP(3, ks + 3)
+    OVN_C2_STEP(4, ks + 4)
+    OVN_C2_STEP(5, ks + 5)
   }
 #undef OVN_C2_STEP
 #undef OVN_LOAD_A
@@ -996,7 +1015,7 @@ __global__ __launch_bounds__(256, 2) void delta_c2_f16x3_kernel(const float* __r
   // a workgroup's 192 rows belong to ONE pair (576 = 3 x 192): its scale and the pointers to its linear terms are wave-uniform
   // (scalar loads, issued here and long landed when the epilogue needs them)
   static_assert((G * G) % C2_TILE_ROWS == 0, "a c_conv2 workgroup must not straddle two pairs");
-  const int pair = blockIdx.x / (G * G / C2_TILE_ROWS);
+  const int pair = blockIdx.x / (G * G / WG_ROWS);
   const float inv2 = scales[2 * pair][3];
   // (pointers loaded from memory are generic to the compiler: as flat loads they would force vmcnt(0) lgkmcnt(0) waits into the
   // K loop's prefetch chain -- 0.60 -> 0.67 ms; say that they are global)
@@ -1047,11 +1066,11 @@ static int pick_nsplit(int n) {
   // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
   // 5 % of the best (big sweeps keep d = 1: one workgroup per pair)
   double best = 1e30;
-  for (const int d : {1, 2, 3, 4, 6, 12}) {
+  for (const int d : {1, 2, 3, 4, 6, 12, 24}) {
     const double cost = (double)(((long long)n * d + 255) / 256) / d;
     if (cost < best) best = cost;
   }
-  for (const int d : {1, 2, 3, 4, 6, 12})
+  for (const int d : {1, 2, 3, 4, 6, 12, 24})
     if ((double)(((long long)n * d + 255) / 256) / d <= 1.05 * best) return d;
   return 1;
 }
@@ -1083,7 +1102,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   p += al((size_t)n * sizeof(DeltaDesc));
   unsigned* qblock = reinterpret_cast<unsigned*>(p);
   *o2max_out = o2max;
-  const int nsplit = pick_nsplit(n);
+  const int nsplit = pick_nsplit(n);   // 24: half-passes (one column group per workgroup), chosen for <= 10 pairs
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
@@ -1103,6 +1122,13 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, desc,         \
                        reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx);                \
   }
+    if (nsplit == 24) {
+      constexpr size_t lds = 2 * (size_t)3 * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;
+      rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<3, 0, 1>), lds);
+      if (rc) return rc;
+      hipLaunchKernelGGL((delta_c1_f16x3_kernel<3, 0, 1>), dim3(n * nsplit), dim3(512), lds, stream, desc,
+                         reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx);
+    } else
 #ifdef OVN_ABLATE
     switch (getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0) {   // tools/experiments/c1_variants.py
       case 2: OVN_C1_LAUNCH(5) break;
@@ -1127,8 +1153,12 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_C2, stream);
     const int total_rows = n * G * G;
-    hipLaunchKernelGGL(delta_c2_f16x3_kernel, dim3(total_rows / C2_TILE_ROWS), dim3(256), 0, stream, o1raw,
-                       reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f);
+    if (n <= 28)   // 9 workgroups of 64 rows per pair, operands several k-steps ahead (a handful of pairs: latency, not throughput)
+      hipLaunchKernelGGL((delta_c2_f16x3_kernel<1, 6, 3>), dim3(total_rows / 64), dim3(256), 0, stream, o1raw,
+                         reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f);
+    else
+      hipLaunchKernelGGL((delta_c2_f16x3_kernel<3, 3, 1>), dim3(total_rows / C2_TILE_ROWS), dim3(256), 0, stream, o1raw,
+                         reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f);
   }
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;

@@ -891,6 +891,28 @@ def test_100k_candidate_sweep_properties(engines):
     assert torch.equal(r2["logit"], r["logit"]) and torch.equal(r2["overlap"], r["overlap"]) and torch.equal(r2["yaw"], r["yaw"])
 
 
+def test_small_sweeps_have_the_bits_of_the_big_sweep(engines):
+    """The Delta kernels pick their workgroup decomposition by sweep size (1 ... 24 workgroups per pair; 24 = one column group each,
+    for the single-pair latency of demo2 / gated demo3 queries): a candidate's result must not depend on it -- every prefix of a
+    300-candidate sweep has the bits of the full sweep, with and without the Delta cache, with and without an index list."""
+    e = engines[4]
+    rng = np.random.default_rng(8)
+    fv = torch.from_numpy(np.maximum(rng.normal(0.2, 1.0, size=(300, 360, 128)), 0).astype(np.float32)).cuda()
+    fv *= torch.from_numpy(rng.uniform(0.5, 2.0, size=(300, 1, 1)).astype(np.float32)).cuda()
+    q = fv[7:8].contiguous()
+    spec, qs, dc = e.spectrum(fv), e.spectrum(fv[7:8].contiguous()), e.delta_cache(fv)
+    full = e.heads(fv, q, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
+    for n in (1, 2, 3, 10, 11, 21, 40, 86, 129):
+        for kw in ({}, {"dcache_l": dc[:n].contiguous()}):
+            r = e.heads(fv[:n].contiguous(), q, spec_l=spec[:n].contiguous(), spec_r=qs, want_logit=True, **kw)
+            assert torch.equal(r["logit"], full["logit"][:n]) and torch.equal(r["yaw"], full["yaw"][:n]), (n, bool(kw))
+        idx = np.arange(n, dtype=np.int32)
+        r = e.heads(fv, q, lidx=idx, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
+        assert torch.equal(r["logit"], full["logit"][:n]), n
+    one = e.heads(fv, q, lidx=np.array([200], np.int32), spec_l=spec, spec_r=qs, want_logit=True)      # a single pair far into the pool
+    assert torch.equal(one["logit"], full["logit"][200:201])
+
+
 def test_head_results_do_not_depend_on_the_launch_structure(engines):
     """ovn_set_head_pipeline (chunk / sub-chunk sizes, one or two streams, yaw head on a side stream) changes WHEN kernels run,
     never what they compute: every pair gets the same bits; and ovn_heads_spectral == ovn_delta_head + ovn_corr_head_spectral."""
