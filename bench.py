@@ -458,7 +458,8 @@ def main():
         same = True
         for s0 in wins:
             n_w = min(64, P - s0)
-            a = eng.heads(cands[s0:s0 + n_w], fvq, spec_l=cand_spec[s0:s0 + n_w], spec_r=spq) if spectral else eng.heads(cands[s0:s0 + n_w], fvq)
+            li = np.arange(s0, s0 + n_w, dtype=np.int32)      # an index list into the block: every candidate keeps its slot
+            a = eng.heads(cands, fvq, lidx=li, spec_l=cand_spec, spec_r=spq) if spectral else eng.heads(cands, fvq, lidx=li)
             same = same and bool(torch.equal(a["overlap"], res[0][s0:s0 + n_w].to(a["overlap"].dtype)) and
                                  torch.equal(a["yaw"].long(), res[1][s0:s0 + n_w].long()))
         out["same_results_without_delta_cache"] = same
@@ -644,7 +645,7 @@ def main():
     rl["step_pairs_per_s"] = out["value"]
     if prof.get("corr_spectral", (0, 0))[1] and spectral:
         ms_in = prof["corr_spectral"][0] / prof["corr_spectral"][1]
-        pairs_in = n_total // max(world, 1) if strong else P
+        pairs_in = P
         rl["corr_in_step_ms"] = ms_in
         rl["corr_in_step_frac_of_hbm_peak"] = pairs_in * CAND_BYTES_PER_PAIR / (ms_in * 1e-3) / PEAK_HBM_BPS
     for name, keys in (("warm_serial", ("value",)), ("fp32_mode", ("value", "overlap_maxerr_vs_oracle")),
