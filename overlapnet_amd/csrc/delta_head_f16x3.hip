@@ -33,7 +33,7 @@
 //   delta_c2_f16x3_kernel       c_conv2 as a streaming GEMM over the (n 576) x 960 matrix of -2 M rows (2.2 MB per pair through HBM)
 // The one-kernel predecessor (o1 image in LDS, c_conv2 as an epilogue phase of every pass: 5.56 ms per 1024 pairs against
 // 4.2 + 0.6 + 0.21 here; its epilogue phase cost 0.93 ms for 0.25 ms of MFMAs, exposed L loads 0.43, W1 register staging 0.35)
-// is kept in tools/experiments/delta_head_f16x3_fused.hip.
+// is in the history (tools/experiments/delta_head_f16x3_fused.hip up to the round-3 tree, commit 170ae22).
 //
 // Scales: weights statically (max |W| -> 2^14), features per PAIR (max over both volumes -> 2^14, so a pair's result does
 // not depend on the other pairs of the call), -2 M by the bound 2 span max_o sum|W1[.,o]|, T by |b1|max + span max_o sum|W1[.,o]|.
