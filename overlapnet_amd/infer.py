@@ -285,6 +285,11 @@ class Infer():
     if vols.size % (FEAT_W * FEAT_C):
       raise ValueError('feature volumes must have shape (n, 1, %d, %d)' % (FEAT_W, FEAT_C))
     vols = np.ascontiguousarray(vols).reshape(-1, FEAT_W, FEAT_C)
+    self._drop_ahead()
+    self._n_frames = vols.shape[0]          # sharded mode: the list holds the volumes of frames 0 .. n-1; the next frame is n
+    if self._world > 1 and vols.shape[0]:   # ... of which this rank keeps the ones it owns, in slot order
+      from . import distributed as D
+      vols = np.ascontiguousarray(vols[D.frame_owner(np.arange(vols.shape[0]), self._world) == self._rank])
     cache = FeatureVolumeCache(self.engine)
     if vols.shape[0]:
       cache.extend_device(torch.from_numpy(vols).to(self.engine.device))

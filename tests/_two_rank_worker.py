@@ -89,6 +89,15 @@ def infer_api(work):
         report["order_error"] = False
     except Exception as ex:
         report["order_error"] = "order" in str(ex)
+    # the reference's way to reset the cache works in sharded mode too: frames start again at 0
+    sh.feature_volumes = []
+    a0 = sh.infer_multiple(0, [])
+    a1 = sh.infer_multiple(1, [0])
+    if rank == 0:
+        ref.feature_volumes = []
+        ref.infer_multiple(0, [])
+        b1 = ref.infer_multiple(1, [0])
+        report["reset_ok"] = bool(a0 is None and np.array_equal(a1[0], b1[0]) and np.array_equal(a1[1], b1[1]) and a1[0].shape == ())
     sh.close()
     if ref is not None:
         ref.close()

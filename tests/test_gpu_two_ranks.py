@@ -60,5 +60,5 @@ def test_sharded_infer_equals_the_unsharded_object(tmp_path, fixture_npz):
     r = _run_two("infer_api", tmp_path)
     assert r["calls"] == frames and r["mismatch"] == [], r
     assert r["local_frames"] == [38, 32]                              # frames 0-31 and 64-69 on rank 0, 32-63 on rank 1
-    assert r["order_error"] is True
+    assert r["order_error"] is True and r["reset_ok"] is True
     assert len(r["best"]) == frames // 5 and any(b[0] is not None for b in r["best"])
