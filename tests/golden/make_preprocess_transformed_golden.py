@@ -47,6 +47,18 @@ for i in range(S.N_TRANSFORMED):
     d = np.linalg.norm(pts[:, :3], 2, axis=1)
     out["n_kept_%d" % i] = int(((d > 0) & (d < 50)).sum())
     print(i, "valid range px %.4f" % np.mean(rng > 0), "valid normal px %.4f" % np.mean(nrm[..., 0] != -1), flush=True)
+# other image geometries / fields of view (the reference's keyword arguments, utils.py:59)
+for k, (ci, _, H, W, up, down, mr) in enumerate(S.GEOMETRY_CASES):
+    pts = S.geometry_cloud(fx, k)
+    rng, vtx, inten, idx = ref_utils.range_projection(pts, fov_up=up, fov_down=down, proj_H=H, proj_W=W, max_range=mr)
+    nrm = ref_utils.gen_normal_map(rng, vtx, proj_H=H, proj_W=W)
+    out["geo_idx_%d" % k] = idx.astype(np.int32)
+    out["geo_sha_range_%d" % k] = sha(rng.astype(np.float32))
+    out["geo_sha_intensity_%d" % k] = sha(inten.astype(np.float32))
+    out["geo_sha_normal_%d" % k] = sha(nrm.astype(np.float32))
+    out["geo_sha_cloud_%d" % k] = sha(pts)
+    print("geometry", k, (H, W, up, down, mr), "valid range px %.4f" % np.mean(rng > 0), "valid normal px %.4f" % np.mean(nrm[..., 0] != -1),
+          "steep points %.3f" % np.mean(np.abs(pts[:, 2]) / np.maximum(np.linalg.norm(pts[:, :3], axis=1), 1e-9) >= 0.5), flush=True)
 dst = os.path.join(HERE, "preprocess_transformed.npz")
 np.savez_compressed(dst, **out)
 print("wrote", dst, os.path.getsize(dst), "bytes")

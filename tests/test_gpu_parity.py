@@ -388,6 +388,25 @@ def test_projection_on_24_transformed_clouds_against_the_reference(engines, fixt
     assert sum(range_diffs) == 0 and sum(tie_diffs) == 10
 
 
+def test_projection_other_geometries_against_the_reference(engines, fixture_npz):
+    """`ovn_project` with the reference's other keyword arguments (32 x 1800, 128 x 2048, 64 x 1024 images, other fields of view and
+    maximum ranges; a +-60 degree field of view on a pitched cloud: arcsin's second branch) against outputs of the reference's own
+    code: identical range images, every image equal to the CPU oracle's."""
+    from overlapnet_amd import preprocess as P
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess_transformed.npz"))
+    for k, (ci, _, H, W, up, down, mr) in enumerate(S.GEOMETRY_CASES):
+        pts = S.geometry_cloud(fixture_npz, k)
+        r = P.project_scans([pts], engine=engines[4], proj_H=H, proj_W=W, fov_up=up, fov_down=down, max_range=mr,
+                            want=("range", "vertex", "intensity", "idx", "normal"))
+        out = {n: v[0].cpu().numpy() for n, v in r.items()}
+        assert out["range"].shape == (H, W) and _sha(out["range"]) == str(g["geo_sha_range_%d" % k]), k
+        o_rng, o_vtx, o_int, o_idx = O.range_projection(pts, fov_up=up, fov_down=down, proj_H=H, proj_W=W, max_range=mr)
+        assert np.array_equal(out["range"], o_rng) and np.array_equal(out["idx"], o_idx) and np.array_equal(out["intensity"], o_int)
+        assert np.array_equal(out["normal"], O.gen_normal_map(o_rng, o_vtx, H, W))
+        if np.array_equal(out["idx"], g["geo_idx_%d" % k]):
+            assert _sha(out["intensity"]) == str(g["geo_sha_intensity_%d" % k]) and _sha(out["normal"]) == str(g["geo_sha_normal_%d" % k])
+
+
 def test_projection_angles_have_numpys_float32_bits(engines, fixture_npz):
     """The two angle functions of utils.py:86-87 on the GPU (csrc/svml_f32.h) against NumPy's own float32 results: the committed
     vectors (arctan2 directly; arcsin through points built to hit given sines) and, through the pinned CPU restatement, every

@@ -110,3 +110,26 @@ def test_transformed_clouds_match_the_reference(fixture_npz):
         f64_range_diffs += int((O.range_projection(pts, trig="f64")[0] != g_rng).sum())
     assert ties == 10            # measured: 20 tie pixels in the 24 clouds, the reference took the higher index in 10 of them
     assert f64_range_diffs == 12  # what rounds 1-3 of the HIP kernel (float64 functions rounded to float32) got wrong
+
+
+def test_other_geometries_match_the_reference(fixture_npz):
+    """The reference's keyword arguments (image size, field of view, maximum range; utils.py:59), incl. a steep field of view on a
+    pitched cloud where 27 % of the points take arcsin's |x| >= 0.5 branch (VRSQRT14PS in NumPy's SVML kernel): identical range
+    images; index differences only at exact depth ties."""
+    from tools import synthetic as S
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess_transformed.npz"))
+    for k, (ci, _, H, W, up, down, mr) in enumerate(S.GEOMETRY_CASES):
+        pts = S.geometry_cloud(fixture_npz, k)
+        assert _sha(pts) == str(g["geo_sha_cloud_%d" % k])
+        rng, vtx, inten, idx = O.range_projection(pts, fov_up=up, fov_down=down, proj_H=H, proj_W=W, max_range=mr)
+        assert rng.shape == (H, W) and _sha(rng) == str(g["geo_sha_range_%d" % k]), k
+        gi = g["geo_idx_%d" % k]
+        x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+        depth = np.sqrt((x * x + y * y) + z * z)
+        dk = depth[(depth > 0) & (depth < mr)]
+        for (r, c) in np.argwhere(idx != gi):
+            assert dk[idx[r, c]] == dk[gi[r, c]]
+        if np.array_equal(idx, gi):
+            assert _sha(inten) == str(g["geo_sha_intensity_%d" % k])
+            assert _sha(O.gen_normal_map(rng, vtx, H, W)) == str(g["geo_sha_normal_%d" % k])

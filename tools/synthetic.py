@@ -195,3 +195,26 @@ def fullstack_cloud(fixture: Dict[str, np.ndarray], i: int) -> np.ndarray:
     """Raw cloud i of bench.py's `fullstack` step (BASELINE configs[4] emulated): shipped scan (i mod 2) rotated about
     z by (37 i mod 900) image columns.  Clouds 0-11 are clouds 0-11 of the preprocessing parity set (`transformed_cloud`)."""
     return z_rotated(fixture["points_%d" % (i % 2)], (37 * i) % 900)
+
+
+# other projection geometries of the preprocessing parity set: (cloud index, extra pitch about y in degrees, proj_H, proj_W, fov_up,
+# fov_down, max_range)
+GEOMETRY_CASES = [
+    (3, 0.0, 32, 1800, 10.0, -30.0, 80),
+    (17, 35.0, 64, 900, 60.0, -60.0, 50),   # steep: the cloud pitched by 35 degrees, |sin(pitch)| >= 0.5 for a third of the points
+    (0, 0.0, 128, 2048, 3.0, -25.0, 120),
+    (20, 0.0, 64, 1024, 2.0, -24.8, 50),
+]
+
+
+def geometry_cloud(fixture: Dict[str, np.ndarray], k: int) -> np.ndarray:
+    """Input cloud of GEOMETRY_CASES[k]: a transformed cloud, optionally pitched further (float64 elementwise, rounded once)."""
+    ci, pitch = GEOMETRY_CASES[k][0], GEOMETRY_CASES[k][1]
+    q = transformed_cloud(fixture, ci)
+    if pitch:
+        b = np.deg2rad(pitch)
+        x, z = q[:, 0].astype(np.float64), q[:, 2].astype(np.float64)
+        q = q.copy()
+        q[:, 0] = (np.cos(b) * x + np.sin(b) * z).astype(np.float32)
+        q[:, 2] = (-np.sin(b) * x + np.cos(b) * z).astype(np.float32)
+    return q
