@@ -2,6 +2,9 @@
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import overlapnet_amd._lib as L
+if len(sys.argv) > 1:
+    L.LIB_PATH = os.path.abspath(sys.argv[1])
 from tools import synthetic as S
 from overlapnet_amd.engine import OvnEngine
 torch.cuda.set_device(0)
@@ -22,4 +25,4 @@ torch.cuda.synchronize()
 ts = []
 for _ in range(7):
     t0 = time.perf_counter(); r = eng.project(P, O, mp, want=(), stacked_flags=(True, True, False)); torch.cuda.synchronize(); ts.append(1e3 * (time.perf_counter() - t0))
-print("OVN_PROJ_MODE=%s projection of 1025 clouds: min %.3f med %.3f ms, checksum %.6e" % (os.environ.get("OVN_PROJ_MODE", "0"), min(ts), sorted(ts)[3], float(r["stacked"].double().sum())))
+print(os.path.basename(L.LIB_PATH), "OVN_PROJ_MODE=%s projection of 1025 clouds: min %.3f med %.3f ms, checksum %.6e" % (os.environ.get("OVN_PROJ_MODE", "0"), min(ts), sorted(ts)[3], float(r["stacked"].double().sum())))
