@@ -17,7 +17,7 @@ __global__ void k_hist(int* hist) { if (threadIdx.x == 0) atomicAdd(&hist[(block
 //         mode 1: same mapping, workgroup scope (WRONG across XCDs -- timing only)
 //         mode 2: image chosen so that all its blocks share blockIdx % 8 (XCD-private), agent scope
 //         mode 3: XCD-private, workgroup scope
-template <int MODE>
+template <int MODE, int SWZ = 0>
 __global__ __launch_bounds__(256) void k_atom(unsigned long long* keys, int img_keys, int blocks_per_img, int n_img, unsigned seed) {
   int b = blockIdx.x, img, blk;
   if (MODE < 2) { img = b / blocks_per_img; blk = b - img * blocks_per_img; }
@@ -28,7 +28,10 @@ __global__ __launch_bounds__(256) void k_atom(unsigned long long* keys, int img_
   const int p = blk * 256 + threadIdx.x;
   unsigned h = (unsigned)p * 2654435761u ^ seed ^ (unsigned)img * 40503u;
   h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
-  const int pix = (int)(((long long)p * img_keys) / ((long long)blocks_per_img * 256) + (h & 3)) % img_keys;
+  int pix = (int)(((long long)p * img_keys) / ((long long)blocks_per_img * 256) + (h & 3)) % img_keys;
+  // SWZ: neighbouring pixels SWZ-way interleaved (pixel i -> slot (i % SWZ) * (img_keys / SWZ) + i / SWZ): the ~28 pixels a wave touches
+  // then lie in ~28 different cache lines (L2 channels) instead of ~5
+  if (SWZ) pix = (pix % SWZ) * (img_keys / SWZ) + pix / SWZ;
   const unsigned long long key = ((unsigned long long)(h >> 8) << 32) | (unsigned)p;
   if (MODE & 1) __hip_atomic_fetch_min(&im[pix], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else __hip_atomic_fetch_min(&im[pix], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -68,6 +71,20 @@ int main() {
     }
     printf("mode %d (%s, %s scope): %.3f ms for %.1f M atomics\n", mode, mode < 2 ? "image on all XCDs" : "XCD-private image",
            (mode & 1) ? "workgroup" : "agent", best, NIMG * (double)BPI * 256 / 1e6);
+  }
+  for (int swz = 0; swz < 3; ++swz) {
+    float best = 1e9f;
+    for (int rep = 0; rep < 5; ++rep) {
+      CK(hipMemset(keys, 0xff, (size_t)NIMG * IMG * 8));
+      CK(hipDeviceSynchronize());
+      CK(hipEventRecord(e0));
+      if (swz == 0) hipLaunchKernelGGL((k_atom<0, 0>), dim3(NIMG * BPI), dim3(256), 0, 0, keys, IMG, BPI, NIMG, 12345u);
+      if (swz == 1) hipLaunchKernelGGL((k_atom<0, 32>), dim3(NIMG * BPI), dim3(256), 0, 0, keys, IMG, BPI, NIMG, 12345u);
+      if (swz == 2) hipLaunchKernelGGL((k_atom<0, 8>), dim3(NIMG * BPI), dim3(256), 0, 0, keys, IMG, BPI, NIMG, 12345u);
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+    }
+    printf("layout %s: %.3f ms for %.1f M atomics (agent scope, image on all XCDs)\n", swz == 0 ? "linear" : swz == 1 ? "32-way interleaved" : "8-way interleaved", best, NIMG * (double)BPI * 256 / 1e6);
   }
   return 0;
 }
