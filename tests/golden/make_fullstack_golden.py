@@ -50,10 +50,12 @@ def main():
     ap.add_argument("--pairs", type=int, default=64)
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count() or 1)
-    ov, yaw, lg = oracle_fullstack(list(range(args.pairs)))
-    path = os.path.join(ROOT, "tests", "golden", "parity_fullstack.npz")
-    np.savez_compressed(path, overlap=ov, yaw=yaw, logit=lg, query_cloud=np.array([QUERY_CLOUD]), channels=np.array([4]))
-    print("wrote %s: %d pairs, logits [%.2f, %.2f], yaw %s ..." % (path, len(ov), lg.min(), lg.max(), yaw[:8]))
+    # the benchmark's weights (file name kept: bench.py reads it) and the trained-like dynamic range (tests/test_parity_sweep.py)
+    for name, fname in (("glorot", "parity_fullstack.npz"), ("trained_like", "parity_fullstack_trained_like.npz")):
+        ov, yaw, lg = oracle_fullstack(list(range(args.pairs)), weights=S.WEIGHT_SETS[name](4))
+        path = os.path.join(ROOT, "tests", "golden", fname)
+        np.savez_compressed(path, overlap=ov, yaw=yaw, logit=lg, query_cloud=np.array([QUERY_CLOUD]), channels=np.array([4]))
+        print("wrote %s: %d pairs, logits [%.2f, %.2f], yaw %s ..." % (path, len(ov), lg.min(), lg.max(), yaw[:8]))
 
 
 if __name__ == "__main__":

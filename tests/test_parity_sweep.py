@@ -127,3 +127,60 @@ def test_sweep_every_pair_against_oracle(wset, C, POOL):
     m = report["modes"]
     assert m["default"]["abs_d_overlap"]["max"] <= 2 * m["all_f32"]["abs_d_overlap"]["max"] + 2e-6, \
         (m["default"]["abs_d_overlap"], m["all_f32"]["abs_d_overlap"])
+
+
+# ---- the full stack: raw clouds -> projection + normals -> leg -> heads (BASELINE configs[4] as bench.py's `fullstack` step runs it) ----
+FULLSTACK = [("glorot", "parity_fullstack.npz"), ("trained_like", "parity_fullstack_trained_like.npz")]
+
+
+@pytest.mark.parametrize("wset,fname", FULLSTACK)
+def test_fullstack_golden_equals_live_oracle_on_sample(wset, fname):
+    """CPU: the committed fp64-oracle outputs of the fullstack step (tests/golden/make_fullstack_golden.py) are what the oracle gives
+    today from the same raw clouds (its own projection with the restated NumPy float32 angles, normals, fp64 leg and heads)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_fullstack_golden", os.path.join(ROOT, "tests", "golden", "make_fullstack_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    with np.load(os.path.join(ROOT, "tests", "golden", fname)) as z:
+        g = {k: z[k] for k in z.files}
+    assert int(g["query_cloud"][0]) == m.QUERY_CLOUD and len(g["overlap"]) == 64
+    ids = [0, 37]
+    ov, yaw, lg = m.oracle_fullstack(ids, weights=S.WEIGHT_SETS[wset](4))
+    np.testing.assert_allclose(ov, g["overlap"][ids], rtol=0, atol=1e-12)
+    assert np.array_equal(yaw, g["yaw"][ids])
+    # the clouds are rotations of the two scans about z: the yaw the network reports follows the rotation (37 columns = 14.8 degrees)
+    assert np.all(np.diff(g["yaw"][:8]) >= 14) and np.all(np.diff(g["yaw"][:8]) <= 19)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wset,fname", FULLSTACK)
+def test_fullstack_from_raw_clouds_against_the_committed_oracle(wset, fname):
+    """GPU: 64 candidates + the query from RAW clouds through `ovn_project` (stacked leg input), the leg and both heads, against the
+    fp64 oracle that started from the same clouds -- the check bench.py makes on its timed `fullstack` step, as a test, for both
+    weight sets and both arithmetic modes."""
+    from overlapnet_amd.engine import OvnEngine
+    from overlapnet_amd import preprocess as P
+    with np.load(os.path.join(ROOT, "tests", "golden", fname)) as z:
+        g = {k: z[k] for k in z.files}
+    fx = S.load_fixture_images()
+    ids = list(range(64)) + [int(g["query_cloud"][0])]
+    e = OvnEngine(64, 900, 4)
+    w = S.WEIGHT_SETS[wset](4)
+    e.load_weights(w, CFG)
+    try:
+        r = P.project_scans([S.fullstack_cloud(fx, i) for i in ids], engine=e, want=(), stacked_flags=(True, True, False))
+        for leg_mode, head_mode, corr in (("f16x3", "f16x3", "spectral"), ("f32", "f32", "direct")):
+            e.set_leg_precision(leg_mode)
+            e.set_head_precision(head_mode)
+            fv = e.leg(r["stacked"])
+            if corr == "spectral":
+                sp = e.spectrum(fv)
+                out = e.heads(fv[:64].contiguous(), fv[64:65].contiguous(), spec_l=sp[:64].contiguous(), spec_r=sp[64:65].contiguous(), want_logit=True)
+            else:
+                out = e.heads(fv[:64].contiguous(), fv[64:65].contiguous(), want_logit=True)
+            ov, yaw, lg = out["overlap"].cpu().numpy(), out["yaw"].cpu().numpy(), out["logit"].cpu().numpy()
+            assert np.max(np.abs(ov - g["overlap"])) <= 1e-4, (leg_mode, float(np.max(np.abs(ov - g["overlap"]))))
+            assert np.array_equal(yaw, g["yaw"])
+            assert np.max(np.abs(lg - g["logit"]) / (1 + np.abs(g["logit"]))) <= 1e-3
+    finally:
+        e.close()
