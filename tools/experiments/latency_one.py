@@ -3,6 +3,9 @@
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import overlapnet_amd._lib as L
+if os.environ.get('OVN_LIB'):
+    L.LIB_PATH = os.path.abspath(os.environ['OVN_LIB'])
 from tools import synthetic as S
 from overlapnet_amd.engine import OvnEngine, decode_match
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1
@@ -23,4 +26,4 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(50): step()
 torch.cuda.synchronize()
-print("N=%d: %.1f us per query" % (N, 1e6 * (time.perf_counter() - t0) / 50))
+print(os.path.basename(L.LIB_PATH), "N=%d: %.1f us per query" % (N, 1e6 * (time.perf_counter() - t0) / 50))
