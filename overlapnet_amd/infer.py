@@ -570,6 +570,9 @@ class Infer():
     query's (feature volume, spectrum) device tensors, valid for the head launches of this call."""
     from . import distributed as D
     fid = int(current_frame_id)
+    if self._n_frames < 0:
+      raise Exception('sharded Infer: infer_multiple_vs_multiple replaced the cache with a replicated one; reset it '
+                      '(infer.feature_volumes = []) before the next sharded sweep')
     if fid != self._n_frames:
       raise Exception('sharded Infer: frames must be fed in order 0, 1, 2, ... (the cache index is the frame id, infer.py:184-190); '
                       'got frame %d, expected %d' % (fid, self._n_frames))
@@ -691,6 +694,10 @@ class Infer():
     file_names = [os.path.basename(v).replace('.bin', '') for v in file_names]
     self.feature_volumes = FeatureVolumeCache(self.engine, min_capacity=len(file_names))
     self.feature_volumes.extend_device(self._leg_device(file_names))
+    if self._world > 1:
+      # replicated on every rank (the pair list is evaluated whole by each): the cache no longer follows the frame ownership of the
+      # sharded sweep -- `infer.feature_volumes = []` before the next infer_multiple / infer_best_match
+      self._n_frames = -1
 
     if len(second_idxs) > 0:
       pair_indizes = np.zeros((len(second_idxs), 2), dtype=int)
