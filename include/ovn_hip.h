@@ -97,7 +97,12 @@ int ovn_leg(ovn_ctx* ctx, const float* images_dev, int64_t n, float* features_de
  *   logit_dev   (n) f32  pre-sigmoid value
  *   corr_dev    (n, feat_w) f32 orientation_output   (generateNet.py:352)
  * Replaces `head.predict_generator` + post-processing (infer.py:155-158,194-198,229-233) and the pair
- * gather of ImagePairOverlapSequenceFeatureVolume.__getitem__ (:43-47). */
+ * gather of ImagePairOverlapSequenceFeatureVolume.__getitem__ (:43-47).
+ * What a pair's bits depend on (f16x3 arithmetic): its two volumes and the left volume's SLOT in feats_l_dev modulo 32 (lidx[p],
+ * or p without an index list) -- not on n, on the chunking of the sweep, on the order of the index list or on the workgroup
+ * decomposition the library picks for small n.  A shard of a pool that starts at a slot which is a multiple of 32 therefore
+ * reproduces the unsharded sweep bit for bit (overlapnet_amd/distributed.py: shard_bounds(align = 32), frame_slot).  The fp32 mode
+ * has one fixed summation order: its bits do not depend on the slot either. */
 int ovn_heads(ovn_ctx* ctx, const float* feats_l_dev, const int32_t* lidx_dev, const float* feats_r_dev,
               const int32_t* ridx_dev, int64_t n, float* overlap_dev, int32_t* yaw_dev, float* logit_dev,
               float* corr_dev, void* stream);
