@@ -38,7 +38,7 @@ constexpr int PLANE = IN_PIX_MAX * 8 + 8;                  // fp16 elements per 
                                                            // bank 0; the fragment reads are unaffected: 0.637 -> 0.625 ms in one run)
 constexpr int NPL = CI / 8;                                // 16 planes
 constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 64;   // hi + lo images + reduction scratch
-constexpr int NW = 8;
+constexpr int NW = 8;                    // waves that split the 256 output channels (2 n-tiles each)
 
 __device__ __forceinline__ int band_start(int b) { return b == 0 ? 0 : (b == 1 ? 8 : 15); }
 __device__ __forceinline__ int band_rows(int b) { return b == 0 ? 8 : 7; }
@@ -46,8 +46,12 @@ __device__ __forceinline__ int band_rows(int b) { return b == 0 ? 8 : 7; }
 // `o2max` (n) holds the float bits of each pair's max o2 value (written by the Delta kernel's epilogue); the patch is scaled by
 // s2 = 2^14 / 2^ceil(log2 max) before the split, the weights were scaled by `sw3` when they were registered, and the
 // accumulators are divided by s2 * sw3 (powers of two: exact).
-template <class A>
-__global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restrict__ o2, const typename A::elem* __restrict__ wp,
+// NWV waves per workgroup: 8 (one workgroup per band: sweeps), or 4 (TWO workgroups per band, each with half of the output channels and
+// its own copy of the patch: one wave per SIMD instead of two -- a handful of pairs are 3 workgroups per pair deep in their own MFMA
+// time, 49 us for a single pair).  The Dense partial sums leave the kernel per (band, half) in both builds and are combined in one
+// fixed order by dense_finish_kernel: same bits.
+template <class A, int NWV>
+__global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restrict__ o2, const typename A::elem* __restrict__ wp,
                                                            const float* __restrict__ b3, const float* __restrict__ wd,
                                                            const unsigned* __restrict__ o2max, float sw3,
                                                            float* __restrict__ partial, float* __restrict__ o3) {
@@ -59,15 +63,18 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   elem_t* il = ih + NPL * PLANE;
   float* red = reinterpret_cast<float*>(il + NPL * PLANE);
 
-  const int pair = blockIdx.x / NBAND;
-  const int band = blockIdx.x - pair * NBAND;
+  constexpr int HALVES = NW / NWV;
+  const int unit = blockIdx.x / HALVES, half = blockIdx.x - unit * HALVES;
+  const int pair = unit / NBAND;
+  const int band = unit - pair * NBAND;
   const int r0 = band_start(band);
   const int nrows = band_rows(band);
   const int npix = nrows * OW;                 // output pixels of this band
   const int nmt = (npix + 15) >> 4;            // 11 or 10
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave_l = tid >> 6;                 // wave within the workgroup
+  const int wave = wave_l + NWV * half;        // wave of the band: output channels 32 wave .. 32 wave + 31
   const int lrow = lane & 15;
   const int g = lane >> 4;
 
@@ -91,17 +98,17 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
     const float* src = o2 + ((long long)pair * G + r0) * G * CI;     // rows r0 .. r0 + nrows + 1, contiguous in NHWC
     const int n4 = (nrows + 2) * G * CI / 4;
     // all of a thread's loads are issued before the first is used: one memory round trip per workgroup instead of fifteen
-    constexpr int PER_THREAD = (MAX_ROWS + 2) * G * CI / 4 / (64 * NW);   // 15
-    static_assert(PER_THREAD * 64 * NW == (MAX_ROWS + 2) * G * CI / 4, "patch does not divide over the threads");
+    constexpr int PER_THREAD = (MAX_ROWS + 2) * G * CI / 4 / (64 * NWV);   // 15 (30 with four waves)
+    static_assert(PER_THREAD * 64 * NWV == (MAX_ROWS + 2) * G * CI / 4, "patch does not divide over the threads");
     f32x4 v[PER_THREAD];
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
-      const int i = tid + k * (64 * NW);
+      const int i = tid + k * (64 * NWV);
       v[k] = (i < n4) ? *reinterpret_cast<const f32x4*>(src + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int k = 0; k < PER_THREAD; ++k) {
-      const int i = tid + k * (64 * NW);
+      const int i = tid + k * (64 * NWV);
       if (i < n4) {
         const int pix = i / (CI / 4);
         const int c = 4 * (i - pix * (CI / 4));
@@ -222,10 +229,17 @@ __global__ __launch_bounds__(64 * NW) void c3_dense_kernel(const float* __restri
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) red[wave] = s;
+  if (lane == 0) red[wave_l] = s;
   __syncthreads();
+  // partial[pair][band][half of the output channels]: (w0 + w1) + (w2 + w3) of each half
   if (tid == 0) {
-    partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    float* dst = partial + ((size_t)pair * NBAND + band) * 2;
+    if (NWV == NW) {
+      dst[0] = (red[0] + red[1]) + (red[2] + red[3]);
+      dst[1] = (red[4] + red[5]) + (red[6] + red[7]);
+    } else {
+      dst[half] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
   }
 }
 
@@ -233,22 +247,31 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            float* __restrict__ overlap, float* __restrict__ logit) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
-  const float z = ((partial[NBAND * p] + partial[NBAND * p + 1]) + partial[NBAND * p + 2]) + bd[0];
+  const float* q = partial + (size_t)p * (2 * NBAND);
+  const float z = (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5])) + bd[0];   // bands in order, each = its two channel halves
   if (logit) logit[p] = z;
   overlap[p] = 1.0f / (1.0f + expf(-z));
 }
 
 }  // namespace
 
-// o2 (n,24,24,128) fp32 -> partial (3 n) Dense partial sums per output-row band [+ o3 (n,22,22,256) when not NULL];
+// o2 (n,24,24,128) fp32 -> partial (6 n) Dense partial sums per (output-row band, half of the output channels) [+ o3 (n,22,22,256) when not NULL];
 // ovn_dense_finish_forward turns the partials into logit / overlap.
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
                          hipStream_t stream) {
   OVN_REQUIRE(o2max != nullptr, OVN_ERR_ARG, "ovn_c3_dense_forward: the per-pair maxima of o2 are required");
-  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16>), LDS_BYTES);
-  if (rc) return rc;
-  hipLaunchKernelGGL(c3_dense_kernel<ArithF16>, dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
-                     reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
+  int rc;
+  if (n <= 42) {   // a handful of pairs: two 4-wave workgroups per band (6 n <= 252 workgroups: still one round, one per CU)
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, 4>), LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL((c3_dense_kernel<ArithF16, 4>), dim3(2 * NBAND * n), dim3(64 * 4), LDS_BYTES, stream, o2,
+                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
+  } else {
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, NW>), LDS_BYTES);
+    if (rc) return rc;
+    hipLaunchKernelGGL((c3_dense_kernel<ArithF16, NW>), dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
+                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
+  }
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

@@ -921,7 +921,7 @@ def test_small_sweeps_have_the_bits_of_the_big_sweep(engines):
     q = fv[7:8].contiguous()
     spec, qs, dc = e.spectrum(fv), e.spectrum(fv[7:8].contiguous()), e.delta_cache(fv)
     full = e.heads(fv, q, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
-    for n in (1, 2, 3, 10, 11, 21, 40, 86, 129):
+    for n in (1, 2, 3, 10, 11, 21, 28, 29, 42, 43, 86, 129):      # (either side of every size at which a kernel changes its decomposition)
         for kw in ({}, {"dcache_l": dc[:n].contiguous()}):
             r = e.heads(fv[:n].contiguous(), q, spec_l=spec[:n].contiguous(), spec_r=qs, want_logit=True, **kw)
             assert torch.equal(r["logit"], full["logit"][:n]) and torch.equal(r["yaw"], full["yaw"][:n]), (n, bool(kw))
