@@ -459,6 +459,7 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_
 
 }  // namespace
 
+constexpr int SMALL_NB = 4;   // calls of at most this many scans take the narrow-tile instantiations below
 static int pad_rows(int ow, int tw) { return (ow + tw - 1) / tw * tw - ow; }   // padded output pixels per row with tiles of tw
 
 // True when ovn_conv_strip_try will run this layer with a kernel that scales its input by the strip's own maximum (s_conv1 at
@@ -495,11 +496,21 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
     // s_conv3 / s_conv3a: workgroups of FOUR waves (one per n-tile, all m-tiles of a narrow tile each) -- three / two of them share a CU,
     // so one stages or stores while another is in its K loop (the 8-wave, one-per-CU tiles of 208 / 135 pixels: +3 % leg time;
     // same K order per accumulator, identical bits)
-    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64: rc = launch_strip<32, 3, 2, 15, 104, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;   // s_conv3
-    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64: rc = launch_strip<64, 3, 2, 12, 64, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took); break;    // s_conv3a
+    // (a call of a few scans -- the query of a loop-closure step -- takes narrower tiles: these kernels scale by the SCAN's maximum, so
+    // the tile width does not change a bit; more workgroups, each with less to do)
+    case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64:   // s_conv3
+      rc = (nb <= SMALL_NB) ? launch_strip<32, 3, 2, 15, 52, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                            : launch_strip<32, 3, 2, 15, 104, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      break;
+    case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64:   // s_conv3a
+      rc = (nb <= SMALL_NB) ? launch_strip<64, 3, 2, 12, 32, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                            : launch_strip<64, 3, 2, 12, 64, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      break;
     // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
     case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
       // 128 registers per lane: two of these 45 KB workgroups per CU (with 144 registers only one fits; 1 % of the leg)
+      if (nb <= SMALL_NB) rc = launch_strip<64, 2, 2, 9, 32, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      else
       rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
                                                                  : launch_strip<64, 2, 2, 9, 96, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
