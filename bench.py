@@ -23,6 +23,12 @@ N > 1: BASELINE.json configs[3], STRONG scaling: one 1-vs-100000 synthetic candi
 contiguous blocks over the ranks (overlapnet_amd.distributed.shard_bounds), feature volumes generated on the device
 (SURVEY.md 8d), one RCCL gather of (overlap, yaw) to rank 0 per step; value = pool_total * steps / elapsed.
 `--pool-total 0` gives the weak-scaling variant (P candidates per rank).  Prints ONE JSON line on rank 0.
+
+`--rehearsal` (or OVN_BENCH_REHEARSAL=1) with N > 1: the SAME command path -- launcher, one rank per "GPU", shard bounds, per-step
+gather to rank 0, every rank's self-check, rank-0-only JSON -- with all N ranks on ONE device and gloo / host tensors in the
+collectives (RCCL refuses two ranks on one device); rank 0 then evaluates the whole pool in one process and requires the gathered
+(overlap, yaw) to be `torch.equal` to it.  The line is marked `"rehearsal": true` and carries no pairs/s (`value` is null): N
+processes time-sharing one GPU say nothing about scaling.
 """
 import argparse
 import json
@@ -69,10 +75,9 @@ DTYPE_LABEL = {
 }
 
 
-def rocprof_traffic(kernel_prefix: str):
-    """HBM bytes per launch of the kernel whose name starts with `kernel_prefix`, from the NEWEST committed rocprofv3
-    PMC summary under profiles/ (separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md;
-    see tools/summarize_rocprof.py) -- null if no summary names it.  Counters cannot be read live in-process."""
+def _committed_traffic(kernel_prefix: str):
+    """(HBM bytes per launch, profile tag) of the kernel whose name starts with `kernel_prefix` from the NEWEST committed
+    rocprofv3 PMC summary under profiles/ (tools/summarize_rocprof.py) -- (None, None) if no summary names it."""
     import glob
     import re
 
@@ -87,8 +92,109 @@ def rocprof_traffic(kernel_prefix: str):
             continue
         hits = [v["total_bytes"] for k, v in t.items() if k.startswith(kernel_prefix)]
         if hits:
-            return max(hits)
-    return None
+            return max(hits), "profiles/" + os.path.basename(f)
+    return None, None
+
+
+def _measured_traffic(kernel_prefix: str, extra_args, timeout_s: float = 150.0):
+    """HBM bytes per launch of the dominant kernel measured NOW: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one
+    pass on gfx950; kernel trace only, no other trace domain) over a short run of this same program, read back from the rocpd
+    database; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section: gfx950 tallies the 128-B requests of wide coalesced reads at
+    64 B), both counters in KiB.  Returns (bytes, {"read": .., "write": ..}) or (None, reason)."""
+    import glob
+    import shutil
+    import sqlite3
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.isfile("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="ovn_traffic_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out_dir, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--traffic", "none"] + list(extra_args)
+            env = dict(os.environ, TMPDIR="/tmp")
+            try:
+                p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+                try:
+                    p.wait(timeout=timeout_s)
+                except subprocess.TimeoutExpired:
+                    import signal
+                    os.killpg(p.pid, signal.SIGKILL)       # the process group WE started, nothing else
+                    p.wait()
+                    return None, "rocprofv3 pass %s timed out after %d s" % (ctr, timeout_s)
+            except OSError as e:
+                return None, "rocprofv3: %s" % e
+            dbs = glob.glob(os.path.join(out_dir, "**", "*.db"), recursive=True)
+            if not dbs:
+                return None, "rocprofv3 pass %s left no database (rc %s)" % (ctr, p.returncode)
+            vals = []
+            for db in dbs:
+                try:
+                    con = sqlite3.connect(db)
+                    q = "select value from counters_collection where counter_name = ? and kernel_name like ? order by dispatch_id"
+                    vals += [r[0] for r in con.execute(q, (ctr, "%" + kernel_prefix + "%"))]
+                    con.close()
+                except sqlite3.Error as e:
+                    return None, "rocpd database: %s" % e
+            if not vals:
+                return None, "no %s rows for %s" % (ctr, kernel_prefix)
+            tail = vals[-3:]                               # the timed steps' launches
+            got[ctr] = sum(tail) / len(tail) * 1024.0      # KiB -> B
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = 2.0 * got["FETCH_SIZE"], got["WRITE_SIZE"]
+    return rd + wr, {"read_bytes": rd, "write_bytes": wr}
+
+
+def rocprof_traffic(kernel_prefix: str, mode: str, extra_args):
+    """-> (bytes per launch or None, where the figure comes from).  mode: 'measure' (PMC passes now, committed profile if they
+    fail), 'committed', 'none'."""
+    if mode == "none":
+        return None, "not collected (--traffic none)"
+    if mode == "measure":
+        b, info = _measured_traffic(kernel_prefix, extra_args)
+        if b is not None:
+            return b, dict(info, source="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes inside this run (2 x FETCH_SIZE, gfx950 correction)")
+        note = info
+    else:
+        note = "not measured (--traffic committed)"
+    b, src = _committed_traffic(kernel_prefix)
+    return b, {"source": src, "note": note}
+
+
+def cpu_baseline_preprocess(n_scans: int = 3):
+    """the reference's NumPy preprocessing (`range_projection` + `gen_normal_map`, utils.py:59-186)
+    timed beside the HIP scatter, on this host.  kind 'port': the oracle's restatement (vectorised projection; the normal map is the
+    reference's per-pixel Python loop restated with array operations, so this baseline FLATTERS the CPU); kind 'reference': the
+    reference's own `utils.py` when OVERLAPNET_REFERENCE names a checkout of PRBonn/OverlapNet (never set on the bench box)."""
+    from oracle import overlapnet_oracle as O
+    fx = S.load_fixture_images()
+    clouds = [S.fullstack_cloud(fx, i) for i in range(n_scans)]
+    kind, proj, normals = "port", O.range_projection, O.gen_normal_map
+    ref_root = os.environ.get("OVERLAPNET_REFERENCE")
+    if ref_root and os.path.isfile(os.path.join(ref_root, "src", "utils", "utils.py")):
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("_ref_utils", os.path.join(ref_root, "src", "utils", "utils.py"))
+            mod = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(mod)
+            kind, proj, normals = "reference", mod.range_projection, mod.gen_normal_map
+        except Exception:
+            pass
+    proj(clouds[0])
+    t0 = time.perf_counter()
+    for c in clouds:
+        r = proj(c)
+    t_proj = (time.perf_counter() - t0) / len(clouds)
+    t0 = time.perf_counter()
+    normals(r[0], r[1])
+    t_norm = time.perf_counter() - t0
+    return {"value": 1.0 / (t_proj + t_norm), "unit": "scans/s", "cores": 1, "kind": kind,
+            "sample": "%d KITTI-sized clouds through range_projection (%.4f s/scan) + one gen_normal_map (%.4f s/scan), single thread "
+                      "as shipped" % (len(clouds), t_proj, t_norm)}
 
 
 def cpu_baseline(channels: int, pool: int):
@@ -171,7 +277,7 @@ def timed(step, warmup, steps, eng, use_dist, dev, side_eng=None):
         for k, (ms, cnt) in side_eng.profile_end().items():
             prof[k] = (prof[k][0] + ms, prof[k][1] + cnt)
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, prof, res
@@ -222,6 +328,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-query", action="store_true", help="warm mode: the query leg on the heads' stream, in front of them (no QueryAhead)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32_mode / cold / fullstack / corr_head sub-records")
+    ap.add_argument("--rehearsal", action="store_true", default=os.environ.get("OVN_BENCH_REHEARSAL", "") == "1",
+                    help="N > 1 ranks on ONE device, gloo / host collectives: rehearses the driver's multi-GPU command path (no pairs/s claim)")
+    ap.add_argument("--traffic", default="measure", choices=["measure", "committed", "none"],
+                    help="roofline.traffic: two rocprofv3 PMC passes over a short run of this program (default, N = 1 warm mode; falls back "
+                         "to the newest committed profile), the committed profile, or nothing")
     ap.add_argument("--accuracy-pairs", type=int, default=12, help="pairs checked against a LIVE fp64 oracle when no committed "
                                                                   "oracle outputs exist for the configuration (untimed)")
     args = ap.parse_args()
@@ -237,12 +348,22 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     visible = torch.cuda.device_count()
-    if visible < max(world, 1) or local_rank >= visible:
+    rehearsal = bool(args.rehearsal and world > 1)
+    if rehearsal:
+        if visible < 1:
+            raise SystemExit("bench.py --rehearsal: needs one GPU, none visible (rank %d)" % rank)
+        local_rank = 0                      # every rank on the ONE device
+    elif visible < max(world, 1) or local_rank >= visible:
         raise SystemExit("bench.py: %d GPUs needed, %d visible (rank %d)" % (world, visible, rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
-    if use_dist:
+    if rehearsal:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)      # host tensors in the collectives (distributed._comm_device)
+        dist.barrier()
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         # RCCL prints its version banner on STDOUT (C stdio, fully buffered when stdout is a pipe) at communicator creation; this
@@ -343,7 +464,7 @@ def main():
 
     def finish(r):
         if use_dist:
-            return D.gather_scores(r["overlap"], r["yaw"], n_total, align=D.SLOT_ALIGN if strong else 1)
+            return D.gather_scores(r["overlap"], r["yaw"], n_total, align=D.SLOT_ALIGN if strong else 1)      # rank 0: the pool in order
         return r["overlap"], r["yaw"]
 
     def step_warm_serial(img=None):
@@ -409,6 +530,25 @@ def main():
                 streamed_same = bool(torch.equal(rs[0], res[0]) and torch.equal(rs[1], res[1]))
         torch.cuda.synchronize()
 
+    # ---- sharded pool: EVERY rank re-evaluates three windows of its block WITHOUT the Delta cache rows (same bits required; windows
+    #      beyond the first 1024-pair chunk where the block is long enough) and rank 0 collects the verdicts ----
+    shard_check = None
+    if strong and args.mode == "warm" and spectral:
+        own = eng.heads(cands, query_fv, spec_l=cand_spec, spec_r=query_spec, dcache_l=cand_dc)   # query 0 (left by the untimed step)
+        wins = sorted({max(0, min(P - 64, s0)) for s0 in (0, 1024 + 37, P - 64)}) if P > 0 else []
+        same = True
+        for s0 in wins:
+            n_w = min(64, P - s0)
+            li = np.arange(s0, s0 + n_w, dtype=np.int32)      # an index list into the block: every candidate keeps its slot
+            a = eng.heads(cands, query_fv, lidx=li, spec_l=cand_spec, spec_r=query_spec)
+            same = same and bool(torch.equal(a["overlap"], own["overlap"][s0:s0 + n_w]) and torch.equal(a["yaw"], own["yaw"][s0:s0 + n_w]))
+        mine = {"rank": rank, "block": [int(lo), int(hi)], "same": bool(same), "windows": [[int(s0), int(min(64, P - s0))] for s0 in wins]}
+        if use_dist:
+            shard_check = [None] * world
+            dist.all_gather_object(shard_check, mine)
+        else:
+            shard_check = [mine]
+
     if rank != 0:
         if use_dist:
             dist.barrier()
@@ -452,7 +592,7 @@ def main():
                                  else "on the heads' stream, in front of them"),
                    "collective": "RCCL gather of (overlap,yaw) to rank 0 per step" if use_dist else "none"},
         "roofline": {"bound": "mfma", "kernel": kname, "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": rocprof_traffic(kprefix),
+                     "frac": achieved / peak, "traffic": None,
                      "flop_per_launch": flop_per_pair * launch_pairs, "pairs_per_launch": launch_pairs,
                      "avg_launch_ms": avg_ms,
                      "mfma_flops_per_algorithmic_flop": 3 if args.head_precision == "f16x3" else 1,
@@ -464,6 +604,27 @@ def main():
         "head_hbm_gbps_algorithmic": (pairs / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
     }
 
+    if rehearsal:
+        # ---- the gathered sweep of query 0 against ONE process evaluating the whole pool: must be the same bits ----
+        pool_all = torch.empty((n_total, 360, 128), dtype=torch.float32, device=dev)
+        for r_ in range(world):
+            lo_r, hi_r = D.shard_bounds(pool_total, world, r_, D.SLOT_ALIGN)
+            g_r = torch.Generator(device=dev).manual_seed(1234 + r_)
+            for s_ in range(0, hi_r - lo_r, 4096):
+                n_ = min(4096, hi_r - lo_r - s_)
+                pool_all[lo_r + s_:lo_r + s_ + n_] = torch.relu(torch.randn((n_, 360, 128), device=dev, generator=g_r) + 0.1)
+        full = eng.heads(pool_all, query_fv, spec_l=eng.spectrum(pool_all), spec_r=query_spec, dcache_l=eng.delta_cache(pool_all))
+        out["rehearsal"] = True
+        out["rehearsal_report"] = {
+            "ranks": world, "devices": 1, "backend": dist.get_backend(),
+            "gather_equals_single_process": bool(torch.equal(res[0].cpu(), full["overlap"].cpu())
+                                                 and torch.equal(res[1].cpu().long(), full["yaw"].cpu().long())),
+            "gathered": int(res[0].numel()), "pairs_per_s_all_ranks_sharing_one_gpu": out["value"],
+            "note": "all ranks time-share ONE GPU over gloo / host collectives: the command path of the multi-GPU run, not a scaling "
+                    "measurement; no N > 1 RCCL run exists"}
+        out["value"] = None
+        del pool_all, full
+
     # ---- accuracy part of the metric ("overlap MAE vs ref"), untimed ----
     ov = res[0].float().cpu().numpy()
     yw = res[1].cpu().numpy()
@@ -471,21 +632,15 @@ def main():
                  and os.path.isfile(os.path.join(ROOT, "tests", "golden", "parity_sweep_glorot.npz")))
     if golden_ok:
         out.update(golden_accuracy(ov[:P], yw[:P]))
-    elif strong and qa is not None:
-        # sharded pool (no committed oracle outputs): this rank's block again WITHOUT the Delta cache rows, in 3 windows that lie
-        # beyond the first 1024-pair chunk where the block is long enough -- same bits required -- and a live fp64 oracle on a few
-        # of those pairs
-        fvq, spq = query_fv, query_spec          # query 0, left there by the untimed step above
-        wins = sorted({max(0, min(P - 64, s0)) for s0 in (0, 1024 + 37, P - 64)})
-        same = True
-        for s0 in wins:
-            n_w = min(64, P - s0)
-            li = np.arange(s0, s0 + n_w, dtype=np.int32)      # an index list into the block: every candidate keeps its slot
-            a = eng.heads(cands, fvq, lidx=li, spec_l=cand_spec, spec_r=spq) if spectral else eng.heads(cands, fvq, lidx=li)
-            same = same and bool(torch.equal(a["overlap"], res[0][s0:s0 + n_w].to(a["overlap"].dtype)) and
-                                 torch.equal(a["yaw"].long(), res[1][s0:s0 + n_w].long()))
-        out["same_results_without_delta_cache"] = same
-        out["same_results_windows"] = [[int(s0), int(min(64, P - s0))] for s0 in wins]
+    elif strong and shard_check is not None:
+        # sharded pool (no committed oracle outputs): the verdicts of EVERY rank's self-check (above), and a live fp64 oracle on a few
+        # pairs of rank 0's block
+        fvq = query_fv                          # query 0, left there by the untimed step above
+        wins = [w0 for w0, _ in shard_check[0]["windows"]]
+        out["same_results_without_delta_cache"] = bool(all(c["same"] for c in shard_check))
+        out["same_results_ranks"] = [bool(c["same"]) for c in shard_check]
+        out["same_results_windows"] = shard_check[0]["windows"]
+        out["shard_blocks"] = [c["block"] for c in shard_check]
         if args.accuracy_pairs > 0:
             from oracle import overlapnet_oracle as O
             k = min(args.accuracy_pairs, 4)
@@ -569,6 +724,9 @@ def main():
                             "step": "projection + normals of %d raw clouds, %d legs, spectra, %d head pairs" % (P + 1, P + 1, P),
                             "projection_ms_per_step": p4["projection"][0] / sub_steps,
                             "projection_scans_per_s": (P + 1) / (p4["projection"][0] / sub_steps * 1e-3)}
+        # per scan 16 B per point in + 64 x 900 x (1 + 3 + 1) x 4 B of images out
+        proj_bytes = 16.0 * float(raw2[1][-1].item()) + (P + 1) * 64 * 900 * 5 * 4
+        out["fullstack"]["projection_frac_of_hbm_peak"] = proj_bytes / (p4["projection"][0] / sub_steps * 1e-3) / PEAK_HBM_BPS
         fs_golden = os.path.join(ROOT, "tests", "golden", "parity_fullstack.npz")
         if P == 1024 and C == 4 and os.path.isfile(fs_golden):
             # the timed fullstack step's own results against the fp64 oracle that started from the same raw clouds (committed
@@ -661,38 +819,77 @@ def main():
                        "pair); ms_per_query = one isolated query (leg, spectrum, heads, decision back to back); ms_per_query_streamed = per "
                        "query of a stream whose next leg runs beside the current heads (QueryAhead), decision still read every query")
         out["latency"] = lat
-    # the scalars DESIGN.md quotes, copied into `roofline` (the driver's record keeps that object verbatim; sub-records survive there
-    # as key names only): all measured in THIS run
-    rl = out["roofline"]
+    # ---- HBM traffic of the dominant kernel: measured now (two rocprofv3 PMC passes over a short run of this program) when this is the
+    #      default single-GPU warm configuration, else the newest committed profile; never silently ----
+    traffic_mode = args.traffic if (world == 1 and not strong and args.mode == "warm" and not args.no_extras) else \
+        ("none" if args.traffic == "none" else "committed")
+    pass_args = ["--pool", str(P), "--channels", str(C), "--head-precision", args.head_precision, "--corr", args.corr]
+    t_bytes, t_src = rocprof_traffic(kprefix, traffic_mode, pass_args)
+    # the scalars DESIGN.md quotes, copied into `roofline`: the driver's record keeps the first ~24 keys of that object (names cut at 40
+    # characters, strings at 120), sub-records survive only as key names -- so the object is built in ORDER OF IMPORTANCE; all measured
+    # in THIS run
+    rl0 = out["roofline"]
+    rl0["traffic"] = t_bytes
+    rl = {k: rl0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frac_executed")}
+    rl["traffic_from"] = (t_src.get("source") or "none") if isinstance(t_src, dict) else str(t_src)
     rl["step_pairs_per_s"] = out["value"]
+
+    def sub(name, key, as_name):
+        if name in out and key in out[name]:
+            rl[as_name] = out[name][key]
+    sub("cold", "value", "cold_pairs_per_s")
+    sub("cold", "leg_scans_per_s", "cold_leg_scans_per_s")
+    sub("cold", "leg_frac_of_16bit_mfma_peak_algorithmic", "cold_leg_frac_of_mfma_peak")
+    sub("fullstack", "value", "fullstack_pairs_per_s")
+    sub("fullstack", "projection_scans_per_s", "fullstack_projection_scans_per_s")
+    sub("fullstack", "projection_frac_of_hbm_peak", "projection_frac_of_hbm_peak")
+    sub("fullstack", "overlap_maxerr_vs_oracle", "fullstack_overlap_maxerr_vs_oracle")
+    if "overlap_maxerr_vs_oracle" in out:
+        rl["overlap_maxerr_vs_oracle"] = out["overlap_maxerr_vs_oracle"]
     if prof.get("corr_spectral", (0, 0))[1] and spectral:
         ms_in = prof["corr_spectral"][0] / prof["corr_spectral"][1]
-        pairs_in = P
-        rl["corr_in_step_ms"] = ms_in
-        rl["corr_in_step_frac_of_hbm_peak"] = pairs_in * CAND_BYTES_PER_PAIR / (ms_in * 1e-3) / PEAK_HBM_BPS
-    for name, keys in (("warm_serial", ("value",)), ("fp32_mode", ("value", "overlap_maxerr_vs_oracle")),
-                       ("cold", ("value", "leg_scans_per_s", "leg_frac_of_16bit_mfma_peak_algorithmic")),
-                       ("fullstack", ("value", "projection_scans_per_s", "overlap_maxerr_vs_oracle", "yaw_exact_rate"))):
-        for k in keys:
-            if name in out and k in out[name]:
-                rl["%s_%s" % (name, "pairs_per_s" if k == "value" else k)] = out[name][k]
+        rl["corr_in_step_frac_of_hbm_peak"] = P * CAND_BYTES_PER_PAIR / (ms_in * 1e-3) / PEAK_HBM_BPS
     if "corr_head" in out and "n16384" in out["corr_head"]:
         rl["corr_n16384_frac_of_hbm_peak"] = out["corr_head"]["n16384"]["frac_of_8TBps"]
     if "latency" in out:
-        for n_c in (1, 100):
-            rec = out["latency"].get("n%d" % n_c, {})
-            if "ms_per_query" in rec:
-                rl["latency_n%d_ms" % n_c] = rec["ms_per_query"]
-            if "ms_per_query_streamed" in rec:
-                rl["latency_n%d_streamed_ms" % n_c] = rec["ms_per_query_streamed"]
+        rec = out["latency"].get("n1", {})
+        if "ms_per_query" in rec:
+            rl["latency_n1_ms"] = rec["ms_per_query"]
+        if "ms_per_query_streamed" in rec:
+            rl["latency_n1_streamed_ms"] = rec["ms_per_query_streamed"]
+    sub("warm_serial", "value", "warm_serial_pairs_per_s")
+    sub("fp32_mode", "value", "fp32_mode_pairs_per_s")
+    # ---- (beyond the driver's 24 keys: kept in the line itself) ----
+    if "yaw_exact_rate" in out:
+        rl["yaw_exact_rate"] = out["yaw_exact_rate"]
     if "infer_api" in out:
         rl["infer_api_frames_per_s"] = out["infer_api"]["api_frames_per_s"]
         rl["infer_api_over_engine"] = out["infer_api"]["api_over_engine"]
-    for k in ("overlap_maxerr_vs_oracle", "yaw_exact_rate", "accuracy_pairs"):
-        if k in out:
-            rl[k] = out[k]
+    sub("fp32_mode", "overlap_maxerr_vs_oracle", "fp32_mode_overlap_maxerr_vs_oracle")
+    sub("fullstack", "yaw_exact_rate", "fullstack_yaw_exact_rate")
+    if "latency" in out:
+        rec = out["latency"].get("n100", {})
+        if "ms_per_query" in rec:
+            rl["latency_n100_ms"] = rec["ms_per_query"]
+        if "ms_per_query_streamed" in rec:
+            rl["latency_n100_streamed_ms"] = rec["ms_per_query_streamed"]
+    if prof.get("corr_spectral", (0, 0))[1] and spectral:
+        rl["corr_in_step_ms"] = prof["corr_spectral"][0] / prof["corr_spectral"][1]
+    if "accuracy_pairs" in out:
+        rl["accuracy_pairs"] = out["accuracy_pairs"]
+    if isinstance(t_src, dict):
+        rl["traffic_detail"] = t_src
+    for k, v in rl0.items():            # flop_per_launch, pairs_per_launch, delta_total_ms, note, ...
+        rl.setdefault(k, v)
+    out["roofline"] = rl
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, P)
+        if not args.no_extras:
+            # the preprocessing half of BASELINE configs[4] on the same host, next to `fullstack`'s projection
+            out["cpu_baseline_preprocess"] = cpu_baseline_preprocess()
+            out["cpu_baseline"]["preprocess_scans_per_s"] = out["cpu_baseline_preprocess"]["value"]
+            out["cpu_baseline"]["preprocess_kind"] = out["cpu_baseline_preprocess"]["kind"]
+            out["roofline"]["cpu_preprocess_scans_per_s"] = out["cpu_baseline_preprocess"]["value"]
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

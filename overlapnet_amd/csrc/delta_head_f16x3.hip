@@ -787,7 +787,8 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 #define OVN_DMA_R(PASS, BUF)                                                                     \
   {                                                                                              \
     const unsigned* rsrc = Rw + (size_t)(PASS) * (JBP * S * FC);                                  \
-    glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);  /* JBP 1: the group's 1920 words + 128 of what follows, never read */ \
+    if (JBP == 2 || tid * 4 < S * FC)   /* JBP 1: exactly the group's S * FC words -- nothing past this pair's packed R block is read */ \
+      glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);                           \
     if (JBP == 2 && wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
   }
 
@@ -1064,14 +1065,17 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
 
 static int pick_nsplit(int n) {
   // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
-  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair)
+  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair).  d = 24 (half-passes: one column group per workgroup) only
+  // for <= 10 pairs, where the 240 workgroups still fit ONE round: a half-pass workgroup walks the whole K / W1 stream like a full
+  // pass does, so it does not cost half a pass and loses as soon as it adds a round (n = 32: 768 workgroups in 3 rounds against
+  // 384 in 2 -- ADVICE r4)
   double best = 1e30;
-  for (const int d : {1, 2, 3, 4, 6, 12, 24}) {
-    const double cost = (double)(((long long)n * d + 255) / 256) / d;
-    if (cost < best) best = cost;
-  }
+  auto cost = [n](int d) { return (double)(((long long)n * d + 255) / 256) / d; };
+  auto allowed = [n](int d) { return d < 24 || n <= 10; };
   for (const int d : {1, 2, 3, 4, 6, 12, 24})
-    if ((double)(((long long)n * d + 255) / 256) / d <= 1.05 * best) return d;
+    if (allowed(d) && cost(d) < best) best = cost(d);
+  for (const int d : {1, 2, 3, 4, 6, 12, 24})
+    if (allowed(d) && cost(d) <= 1.05 * best) return d;
   return 1;
 }
 

@@ -40,19 +40,41 @@ def shard_sizes(n: int, world: int, align: int = 1) -> List[int]:
     return [shard_bounds(n, world, r, align)[1] - shard_bounds(n, world, r, align)[0] for r in range(world)]
 
 
-# ---- ownership of a GROWING cache (Infer.infer_multiple caches one frame per call, infer.py:184-185): block-cyclic --------------
+# ---- ownership of a GROWING cache (Infer.infer_multiple caches one frame per call, infer.py:184-185): skewed block-cyclic ------
 def frame_owner(frame_id, world: int, block: int = SLOT_ALIGN):
-    """Rank that keeps frame `frame_id`'s feature volume / spectrum / Delta row: blocks of `block` consecutive frames go round the
-    ranks.  Contiguous shards cannot be used for a cache that grows by one frame per query (their bounds would move); plain
-    round-robin would change a frame's slot modulo 32.  Works on ints and integer arrays."""
-    return (np.asarray(frame_id) // block) % world if not np.isscalar(frame_id) else (int(frame_id) // block) % world
+    """Rank that keeps frame `frame_id`'s feature volume / spectrum / Delta row: `(f // block + f % block) % world`.
+    Contiguous shards cannot be used for a cache that grows by one frame per query (their bounds would move), and the Delta kernels'
+    summation order needs every frame at a local slot congruent to its id modulo 32 (`frame_slot`).  Dealing whole blocks of 32
+    consecutive frames to one rank (rounds 1-4) satisfies that but puts a GATED reference list -- demo3_lcd.py:92-115 keeps a window
+    of consecutive frame ids -- on one or two ranks; the skew spreads consecutive frames over consecutive ranks and keeps the slot
+    residue: within a round of `world` blocks a rank sees every residue f % block exactly once.  Works on ints and integer arrays."""
+    if np.isscalar(frame_id):
+        f = int(frame_id)
+        return (f // block + f % block) % world
+    f = np.asarray(frame_id)
+    return (f // block + f % block) % world
 
 
 def frame_slot(frame_id, world: int, block: int = SLOT_ALIGN):
-    """Index of frame `frame_id` in its owner's local cache when frames arrive in order 0, 1, 2, ... (slot == frame_id mod block
-    modulo `block`, so the pair (frame, query) gets the unsharded sweep's bits)."""
+    """Index of frame `frame_id` in its owner's local cache: round (of `world` blocks) * block + f % block -- congruent to the frame
+    id modulo `block`, so the pair (frame, query) gets the unsharded sweep's bits.  Slots of a rank are NOT filled in increasing
+    order (frame 8 lands on rank 0's slot 8 long before frame 39 fills its slot 7 at world = 8): the cache is slot-addressed."""
     f = np.asarray(frame_id) if not np.isscalar(frame_id) else int(frame_id)
     return (f // (block * world)) * block + f % block
+
+
+def local_capacity(n_frames: int, world: int, block: int = SLOT_ALIGN) -> int:
+    """Slots a rank's cache needs once frames 0 .. n_frames - 1 have been fed (upper bound: whole rounds)."""
+    return ((int(n_frames) + block * world - 1) // (block * world)) * block
+
+
+def share_imbalance(frame_ids, world: int, block: int = SLOT_ALIGN) -> float:
+    """max / mean of the per-rank share of a reference list (1.0 = perfectly balanced; `world` = everything on one rank)."""
+    f = np.asarray(frame_ids).reshape(-1)
+    if f.size == 0:
+        return 1.0
+    counts = np.bincount(frame_owner(f, world, block), minlength=world)
+    return float(counts.max() * world / f.size)
 
 
 def pack_scores(overlap: torch.Tensor, yaw: torch.Tensor) -> torch.Tensor:
@@ -102,29 +124,35 @@ def _comm_device(t: torch.Tensor, group=None) -> torch.Tensor:
     return t.cpu() if dist.get_backend(group) == "gloo" else t
 
 
-def allgather_by_owner(overlap: torch.Tensor, yaw: torch.Tensor, owner: np.ndarray, group=None
-                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+def allgather_by_owner(overlap: torch.Tensor, yaw: torch.Tensor, owner: np.ndarray, group=None, status: int = 0
+                       ) -> Tuple[torch.Tensor, torch.Tensor, np.ndarray]:
     """Every rank holds the (overlap, yaw) of the list entries it owns (`owner[i]` = rank of entry i, known to all ranks), in list
-    order; ONE all-gather of 8 B per entry (padded to the largest share) gives every rank the whole list in list order."""
+    order; ONE all-gather of 8 B per entry (padded to the largest share, + one status row) gives every rank the whole list in list
+    order and every rank's `status` word (0 = fine): a rank whose local work failed still takes part in the collective (with
+    whatever it holds, or nothing) and ALL ranks learn about it from the same payload, instead of the others blocking in a
+    collective the failed rank never enters.  Returns (overlap, yaw, statuses (world,))."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     owner = np.asarray(owner)
-    counts = [int((owner == r).sum()) for r in range(world)]
-    if overlap.numel() != counts[rank]:
+    counts = np.bincount(owner, minlength=world).astype(np.int64) if owner.size else np.zeros(world, np.int64)
+    if status == 0 and overlap.numel() != counts[rank]:
         raise ValueError("rank %d holds %d scores, it owns %d list entries" % (rank, overlap.numel(), counts[rank]))
-    m = max(counts) if counts else 0
-    payload = torch.zeros((m, 2), dtype=torch.int32, device=overlap.device)
-    if overlap.numel():
+    m = int(counts.max()) if counts.size else 0
+    payload = torch.zeros((m + 1, 2), dtype=torch.int32, device=overlap.device)
+    if status == 0 and overlap.numel():
         payload[:overlap.numel()] = pack_scores(overlap, yaw)
+    payload[m, 0] = int(status)
     payload = _comm_device(payload, group)
     bufs = [torch.empty_like(payload) for _ in range(world)]
     dist.all_gather(bufs, payload, group=group)
+    statuses = torch.stack([b[m, 0] for b in bufs]).cpu().numpy()
+    # list position of the k-th entry of rank r's share = the k-th position whose owner is r: one stable sort, one indexed store
+    order = torch.from_numpy(np.argsort(owner, kind="stable")).to(payload.device)
     out = torch.zeros((len(owner), 2), dtype=torch.int32, device=payload.device)
-    for r in range(world):
-        if counts[r]:
-            out[torch.from_numpy(np.nonzero(owner == r)[0]).to(out.device)] = bufs[r][:counts[r]]
-    return unpack_scores(out)
-
+    if len(owner):
+        out[order] = torch.cat([bufs[r][:int(counts[r])] for r in range(world)], dim=0)
+    ov, yw = unpack_scores(out)
+    return ov, yw, statuses
 
 
 def best_match(overlap: torch.Tensor, yaw: torch.Tensor, threshold: float = 0.3):
@@ -173,7 +201,8 @@ def merge_matches_by_position(records) -> "torch.Tensor":
 
 
 def allgather_records(record: torch.Tensor, group=None) -> torch.Tensor:
-    """(world, 4) int32: every rank's 16-byte best-match record."""
+    """(world, 4) int32: every rank's 16-byte best-match record.  The `found` field (word 3) of a rank whose local work failed
+    carries a negative status instead (see `Infer._infer_best_match_sharded`): every rank sees it in the same payload."""
     world = dist.get_world_size(group)
     rec = _comm_device(record.contiguous(), group)
     bufs = [torch.empty_like(rec) for _ in range(world)]

@@ -500,6 +500,7 @@ class QueryAhead:
                         if with_delta_cache and engine.has_delta_cache else None)
             self._ready = [torch.cuda.Event(), torch.cuda.Event()]
             self._released = [None, None]      # recorded on the consumer's stream behind the last reader of a slot's contents
+            self._has_dc = [False, False]      # did the slot's last submit compute the Delta cache row?
         self._submitted = 0
         self._taken = 0
         self._last = None                      # slot handed out by the latest take(), not yet released
@@ -513,11 +514,12 @@ class QueryAhead:
             self._released[self._last] = ev
             self._last = None
 
-    def submit(self, image: torch.Tensor, wait_current: bool = True) -> None:
+    def submit(self, image: torch.Tensor, wait_current: bool = True, with_delta: bool = True) -> None:
         """Enqueue leg + spectrum of `image` (1, in_h, in_w, in_c) on the side stream; at most two queries may be in flight.
         `wait_current=False`: the image was produced on `self.stream` itself (e.g. its host-to-device copy was issued there), so the
         side stream need not wait for the work already enqueued on the caller's stream -- except for the readers of the slot it is
-        about to overwrite, which it always waits for."""
+        about to overwrite, which it always waits for.  `with_delta=False`: skip this query's Delta cache row even if the object was
+        built `with_delta_cache` (a sharded `Infer` whose rank does not own the frame); `take_all` then returns None for it."""
         if self._submitted - self._taken >= 2:
             raise _lib.OvnError("QueryAhead.submit: two queries are already in flight, take() one first")
         self._release_last()
@@ -533,7 +535,8 @@ class QueryAhead:
         with torch.cuda.stream(self.stream):
             self.side.leg(image, out=self._fv[slot])
             self.side.spectrum(self._fv[slot], out=self._spec[slot])
-            if self._dc is not None:
+            self._has_dc[slot] = self._dc is not None and bool(with_delta)
+            if self._has_dc[slot]:
                 self.side.delta_cache(self._fv[slot], out=self._dc[slot])
             self._ready[slot].record(self.stream)
         image.record_stream(self.stream)
@@ -556,7 +559,7 @@ class QueryAhead:
     def take_all(self):
         """take() plus the Delta cache row (None unless built with `with_delta_cache` on a head geometry that has one)."""
         fv, spec = self.take()
-        return fv, spec, (self._dc[self._last_taken] if self._dc is not None else None)
+        return fv, spec, (self._dc[self._last_taken] if self._has_dc[self._last_taken] else None)
 
     def close(self) -> None:
         self.stream.synchronize()

@@ -57,33 +57,45 @@ class FeatureVolumeCache(object):
     return self._want_dc and self._engine.has_delta_cache
 
   # -- device side ---------------------------------------------------------------------------------
-  def extend_device(self, fv: torch.Tensor, spec: Optional[torch.Tensor] = None, dc: Optional[torch.Tensor] = None) -> None:
-    """Append k volumes; their spectra / Delta cache rows are computed here unless the caller already has them (the streaming path
-    computes them beside the previous frame's head kernels)."""
+  def _grow(self, need: int) -> None:
+    if self._fv is not None and need <= self._fv.shape[0]:
+      return
+    cap = max(self._min_capacity, need if self._fv is None else 2 * need)
+    dev = self._engine.device
+    nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
+    ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
+    nd = torch.empty((cap if self._with_dc else 0, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
+    if self._n:
+      nf[:self._n].copy_(self._fv[:self._n])
+      ns[:self._n].copy_(self._spec[:self._n])
+      if self._with_dc:
+        nd[:self._n].copy_(self._dc[:self._n])
+    self._fv, self._spec, self._dc = nf, ns, nd
+
+  def put_device(self, slot: int, fv: torch.Tensor, spec: Optional[torch.Tensor] = None, dc: Optional[torch.Tensor] = None) -> None:
+    """Write k volumes at slots slot .. slot + k - 1 (slot <= len(self): an append when equal, an overwrite below, and -- the
+    sharded cache, whose slots fill out of order (distributed.frame_slot) -- beyond the end: `len()` then becomes the high-water
+    mark and the slots in between stay unwritten until their frames arrive; nothing refers to a slot before its frame has been fed).
+    Spectra / Delta cache rows are computed here unless the caller already has them (the streaming path computes them beside the
+    previous frame's head kernels)."""
     k = fv.shape[0]
-    if self._fv is None or self._n + k > self._fv.shape[0]:
-      cap = max(self._min_capacity, self._n + k if self._fv is None else 2 * (self._n + k))
-      dev = self._engine.device
-      nf = torch.empty((cap, FEAT_W, FEAT_C), dtype=torch.float32, device=dev)
-      ns = torch.empty((cap, FEAT_C, self._engine.SPEC_W), dtype=torch.float32, device=dev)
-      nd = torch.empty((cap if self._with_dc else 0, self._engine.DELTA_CACHE_ELEMS), dtype=torch.float32, device=dev)
-      if self._n:
-        nf[:self._n].copy_(self._fv[:self._n])
-        ns[:self._n].copy_(self._spec[:self._n])
-        if self._with_dc:
-          nd[:self._n].copy_(self._dc[:self._n])
-      self._fv, self._spec, self._dc = nf, ns, nd
-    self._fv[self._n:self._n + k].copy_(fv)
+    slot = int(slot)
+    self._grow(max(self._n, slot + k))
+    self._fv[slot:slot + k].copy_(fv)
     if spec is not None:
-      self._spec[self._n:self._n + k].copy_(spec)
+      self._spec[slot:slot + k].copy_(spec)
     else:
-      self._engine.spectrum(self._fv[self._n:self._n + k], out=self._spec[self._n:self._n + k])
+      self._engine.spectrum(self._fv[slot:slot + k], out=self._spec[slot:slot + k])
     if self._with_dc:
       if dc is not None:
-        self._dc[self._n:self._n + k].copy_(dc)
+        self._dc[slot:slot + k].copy_(dc)
       else:
-        self._engine.delta_cache(self._fv[self._n:self._n + k], out=self._dc[self._n:self._n + k])
-    self._n += k
+        self._engine.delta_cache(self._fv[slot:slot + k], out=self._dc[slot:slot + k])
+    self._n = max(self._n, slot + k)
+
+  def extend_device(self, fv: torch.Tensor, spec: Optional[torch.Tensor] = None, dc: Optional[torch.Tensor] = None) -> None:
+    """Append k volumes (see put_device)."""
+    self.put_device(self._n, fv, spec=spec, dc=dc)
 
   @property
   def device_features(self) -> torch.Tensor:
@@ -152,10 +164,14 @@ class Infer():
           rank / world / group: extension -- the 1-vs-N sweep of `infer_multiple` / `infer_best_match` sharded over `world`
           processes (one per GPU, torch.distributed initialised by the caller).  Every rank makes the SAME calls
           with the same arguments and gets the same results.  Frame i's feature volume / spectrum / Delta row live on rank
-          `distributed.frame_owner(i)` only (blocks of 32 consecutive frames go round the ranks), the query leg runs on every
-          rank (cheaper than a broadcast), each rank scores the references it owns and ONE all-gather of 8 B per reference (or of
-          one 16-byte best-match record per rank) merges the answer.  Same bits as the unsharded object.  `infer_one`,
-          `infer_multiple_vs_multiple` and `create_feature_volumes` run replicated on every rank.
+          `distributed.frame_owner(i)` only (skewed block-cyclic: consecutive frames go to consecutive ranks, and a frame's local
+          slot stays congruent to its id modulo 32 -- a gated window of consecutive ids, demo3_lcd.py:92-115, is spread evenly),
+          the query leg runs on every rank (cheaper than a broadcast), each rank scores the references it owns and ONE all-gather
+          of 8 B per reference (or of one 16-byte best-match record per rank) merges the answer.  Same bits as the unsharded
+          object.  `infer_one`, `infer_multiple_vs_multiple` and `create_feature_volumes` run replicated on every rank.
+          `len(infer.feature_volumes)` is the rank's LOCAL high-water slot there (not the number of frames fed), and indexing
+          the view addresses local slots.  A failure of one rank's local work (a file missing on that node, a kernel error) is
+          carried in the collective's payload: every rank raises, none is left waiting in the all-gather.
           config['stream_ahead'] (optional, default True): the speculative read + leg of frame i + 1 beside frame i's heads.
     """
     self._rank, self._world, self._group = 0, 1, group
@@ -168,6 +184,8 @@ class Infer():
       if not 0 <= self._rank < self._world or self._world != dist.get_world_size(group):
         raise Exception('Infer: rank %d / world %d do not match the process group' % (self._rank, self._world))
     self._n_frames = 0          # sharded mode: frames fed so far (== the next frame id)
+    # sharded mode: what this rank did (tests assert that the cache-row path was taken, not a per-pair fallback)
+    self.sharded_stats = {'frames_cached': 0, 'pairs_scored': 0, 'pairs_on_cache_rows': 0, 'ahead_delta_rows': 0}
     self._scan_folder = config.get('scan_folder') or None
     if self._scan_folder is not None and config['use_class_probabilities']:
       raise Exception("config['scan_folder']: the semantic channels come from RangeNet++ .npy files, not from the raw scans")
@@ -279,7 +297,12 @@ class Infer():
     """`infer.feature_volumes = []` (the reference's way to reset the cache) or any list / ndarray of (1, 360, 128) host volumes
     rebuilds the device cache from it; a FeatureVolumeCache is taken as is."""
     if isinstance(value, FeatureVolumeCache):
+      self._drop_ahead()
       self._feature_volumes = value
+      if self._world > 1:
+        # a cache built elsewhere does not follow this object's frame ownership (slot = distributed.frame_slot): the sharded
+        # sweeps refuse it until the cache is reset from a list (`infer.feature_volumes = []` or the volumes of frames 0 .. n-1)
+        self._n_frames = -1
       return
     vols = np.asarray(value, dtype=np.float32) if len(value) else np.zeros((0, FEAT_W, FEAT_C), np.float32)
     if vols.size % (FEAT_W * FEAT_C):
@@ -287,11 +310,15 @@ class Infer():
     vols = np.ascontiguousarray(vols).reshape(-1, FEAT_W, FEAT_C)
     self._drop_ahead()
     self._n_frames = vols.shape[0]          # sharded mode: the list holds the volumes of frames 0 .. n-1; the next frame is n
-    if self._world > 1 and vols.shape[0]:   # ... of which this rank keeps the ones it owns, in slot order
-      from . import distributed as D
-      vols = np.ascontiguousarray(vols[D.frame_owner(np.arange(vols.shape[0]), self._world) == self._rank])
     cache = FeatureVolumeCache(self.engine)
-    if vols.shape[0]:
+    if self._world > 1 and vols.shape[0]:   # ... of which this rank keeps the ones it owns, each at its slot
+      from . import distributed as D
+      ids = np.arange(vols.shape[0])
+      mine = ids[D.frame_owner(ids, self._world) == self._rank]
+      slots = D.frame_slot(mine, self._world)
+      for k in np.argsort(slots, kind='stable'):       # increasing slot order; runs of consecutive slots go in one copy
+        cache.put_device(int(slots[k]), torch.from_numpy(vols[mine[k]:mine[k] + 1]).to(self.engine.device))
+    elif vols.shape[0]:
       cache.extend_device(torch.from_numpy(vols).to(self.engine.device))
     self._feature_volumes = cache
 
@@ -515,7 +542,12 @@ class Infer():
       with torch.cuda.stream(self._qa.stream):
         # copies + interleave (or the projection of the raw scan, in the second context's scratch) on the side stream
         x = self._inputs_device(names, engine=self._qa.side)
-      self._qa.submit(x, wait_current=False)
+      want_dc = True
+      if self._world > 1:     # only the frame's owner keeps (and therefore computes) its Delta cache row
+        from . import distributed as D
+        want_dc = bool(D.frame_owner(int(current_frame_id) + 1, self._world) == self._rank)
+        self.sharded_stats['ahead_delta_rows'] += int(want_dc)
+      self._qa.submit(x, wait_current=False, with_delta=want_dc)
       self._ahead_fv = names[0]
       self._ahead_sig = sig
     except Exception:
@@ -565,18 +597,25 @@ class Infer():
     self.feature_volumes.extend_device(self._leg_device([name]))
 
   # ---- sharded 1-vs-N sweep (extension) ------------------------------------------------------------------------------
-  def _query_frame_sharded(self, current_frame_id):
-    """Leg (+ spectrum, Delta row) of the current frame on EVERY rank; the owner appends it to its local cache.  Returns the
-    query's (feature volume, spectrum) device tensors, valid for the head launches of this call."""
-    from . import distributed as D
+  def _check_sharded_frame(self, current_frame_id) -> int:
+    """Argument checks every rank evaluates identically (they raise on all ranks or on none)."""
     fid = int(current_frame_id)
     if self._n_frames < 0:
-      raise Exception('sharded Infer: infer_multiple_vs_multiple replaced the cache with a replicated one; reset it '
+      raise Exception('sharded Infer: the cache was replaced by one that does not follow the frame ownership '
+                      '(infer_multiple_vs_multiple, or a FeatureVolumeCache assigned to infer.feature_volumes); reset it '
                       '(infer.feature_volumes = []) before the next sharded sweep')
     if fid != self._n_frames:
       raise Exception('sharded Infer: frames must be fed in order 0, 1, 2, ... (the cache index is the frame id, infer.py:184-190); '
                       'got frame %d, expected %d' % (fid, self._n_frames))
+    return fid
+
+  def _query_frame_sharded(self, fid: int):
+    """Leg (+ spectrum; the Delta row on the owner only) of the current frame on EVERY rank; the owner writes it to the frame's
+    slot of its local cache.  Returns the query's (feature volume, spectrum) device tensors, valid for the head launches of this
+    call."""
+    from . import distributed as D
     name = str(fid).zfill(6)
+    owned = D.frame_owner(fid, self._world) == self._rank
     if self._ahead_fv == name and self._ahead_sig is not None and self._ahead_sig == self._frame_signature(name):
       self._ahead_fv = None
       fv, spec, dc = self._qa.take_all()
@@ -586,60 +625,104 @@ class Infer():
       fv = self._leg_device([name])
       spec = self.engine.spectrum(fv)
       dc = None
-    self._n_frames += 1
-    if D.frame_owner(fid, self._world) == self._rank:
+    if owned:
       cache = self.feature_volumes
-      cache.extend_device(fv, spec=spec, dc=dc)
-      k = len(cache) - 1
-      assert k == D.frame_slot(fid, self._world)
+      k = int(D.frame_slot(fid, self._world))
+      cache.put_device(k, fv, spec=spec, dc=dc)
+      self.sharded_stats['frames_cached'] += 1
       return cache.device_features[k:k + 1], cache.device_spectra[k:k + 1]
     return fv, spec
 
-  def _local_heads_sharded(self, ref: np.ndarray, q_fv, q_spec):
-    """Heads of the references this rank owns, in list order -> (owner array, result dict or None)."""
+  def _local_heads_sharded(self, ref: np.ndarray, mine: np.ndarray, q_fv, q_spec):
+    """Heads of the references this rank owns, in list order, on their cache rows -> result dict or None."""
     from . import distributed as D
-    if len(ref) and (ref.min() < 0 or ref.max() >= self._n_frames):
-      raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(ref.max()), self._n_frames))
-    owner = D.frame_owner(ref, self._world)
-    mine = owner == self._rank
     if not mine.any():
-      return owner, mine, None
+      return None
     cache = self.feature_volumes
     lidx = np.ascontiguousarray(D.frame_slot(ref[mine], self._world), dtype=np.int32)
+    if int(lidx.max()) >= len(cache):
+      raise OvnError('sharded Infer: reference slot %d beyond the local cache (%d)' % (int(lidx.max()), len(cache)))
+    dcl = cache.device_delta_cache
     r = self.engine.heads(cache.device_features, q_fv, lidx=lidx, n=len(lidx), spec_l=cache.device_spectra, spec_r=q_spec,
-                          dcache_l=cache.device_delta_cache)
-    return owner, mine, r
+                          dcache_l=dcl)
+    self.sharded_stats['pairs_scored'] += int(len(lidx))
+    if dcl is not None:
+      self.sharded_stats['pairs_on_cache_rows'] += int(len(lidx))      # offered to the library with their Delta cache rows
+    return r
+
+  def _sharded_refs(self, reference_frame_id):
+    """(reference ids, owner of each, this rank's mask) -- host arithmetic every rank evaluates identically."""
+    from . import distributed as D
+    ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
+    if len(ref) and (ref.min() < 0 or ref.max() > self._n_frames):     # (the current frame, id == _n_frames, is cached by this call)
+      raise IndexError('index %d is out of bounds for axis 0 with size %d' % (int(ref.max()), self._n_frames + 1))
+    owner = D.frame_owner(ref, self._world) if len(ref) else np.zeros(0, np.int64)
+    return ref, owner, owner == self._rank
+
+  @staticmethod
+  def _raise_rank_failure(statuses, local_error):
+    bad = [int(r) for r in np.nonzero(np.asarray(statuses) != 0)[0]]
+    if local_error is not None:
+      raise local_error
+    if bad:
+      raise Exception('sharded Infer: the local work of rank(s) %s failed (see their own exception); the query is void on every rank' % bad)
 
   def _infer_multiple_sharded(self, current_frame_id, reference_frame_id):
     from . import distributed as D
-    q_fv, q_spec = self._query_frame_sharded(current_frame_id)
-    ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
-    if len(ref) == 0:
-      return None
-    owner, mine, r = self._local_heads_sharded(ref, q_fv, q_spec)
-    self._start_ahead(current_frame_id)
+    fid = self._check_sharded_frame(current_frame_id)
+    ref, owner, mine = self._sharded_refs(reference_frame_id)
     dev = self.engine.device
+    err, r = None, None
+    try:                                      # local work: files, leg, heads -- may fail on ONE rank only
+      q_fv, q_spec = self._query_frame_sharded(fid)
+      if len(ref):
+        r = self._local_heads_sharded(ref, mine, q_fv, q_spec)
+    except Exception as e:                    # noqa: BLE001 -- carried to every rank in the payload below
+      err = e
+    self._n_frames += 1
+    if len(ref) == 0:
+      if err is not None:
+        raise err
+      return None
+    if err is None:
+      self._start_ahead(current_frame_id)
     ov = r["overlap"] if r is not None else torch.empty(0, dtype=torch.float32, device=dev)
     yw = r["yaw"] if r is not None else torch.empty(0, dtype=torch.int32, device=dev)
-    ov_all, yaw_all = D.allgather_by_owner(ov, yw, owner, self._group)
-    overlap = ov_all.cpu().numpy().reshape(-1, 1)
-    return overlap.squeeze(), yaw_all.cpu().numpy().astype(np.int64)
+    ov_all, yaw_all, statuses = D.allgather_by_owner(ov, yw, owner, self._group, status=0 if err is None else 1)
+    self._raise_rank_failure(statuses, err)
+    res = torch.stack([ov_all.view(torch.int32), yaw_all]).cpu().numpy()      # ONE device-to-host copy for both
+    overlap = res[0].view(np.float32).reshape(-1, 1)
+    return overlap.squeeze(), res[1].astype(np.int64)
 
   def _infer_best_match_sharded(self, current_frame_id, reference_frame_id, overlap_thres):
     from . import distributed as D
     from .engine import decode_match
-    q_fv, q_spec = self._query_frame_sharded(current_frame_id)
-    ref = np.asarray(reference_frame_id, dtype=np.int64).reshape(-1)
+    fid = self._check_sharded_frame(current_frame_id)
+    ref, owner, mine = self._sharded_refs(reference_frame_id)
+    err, rec = None, None
+    try:
+      q_fv, q_spec = self._query_frame_sharded(fid)
+      if len(ref):
+        r = self._local_heads_sharded(ref, mine, q_fv, q_spec)
+        if r is not None:   # the record's id field carries the POSITION in the reference list: ties resolve like np.argmax over the list
+          pos = torch.from_numpy(np.nonzero(mine)[0].astype(np.int32)).to(self.engine.device)
+          rec = self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=pos)
+    except Exception as e:                    # noqa: BLE001
+      err = e
+    self._n_frames += 1
     if len(ref) == 0:
+      if err is not None:
+        raise err
       return None
-    owner, mine, r = self._local_heads_sharded(ref, q_fv, q_spec)
-    if r is not None:     # the record's id field carries the POSITION in the reference list: ties resolve like np.argmax over the list
-      pos = torch.from_numpy(np.nonzero(mine)[0].astype(np.int32)).to(self.engine.device)
-      rec = self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=pos)
-    else:
+    if err is not None:
+      rec = torch.tensor([-1, 0, 0, -1], dtype=torch.int32, device=self.engine.device)      # word 3 < 0: this rank failed
+    elif rec is None:
       rec = torch.tensor([-1, 0, 0, 0], dtype=torch.int32, device=self.engine.device)
-    self._start_ahead(current_frame_id)
-    got = decode_match(D.merge_matches_by_position(D.allgather_records(rec, self._group)))
+    if err is None:
+      self._start_ahead(current_frame_id)
+    recs = D.allgather_records(rec, self._group)
+    self._raise_rank_failure((recs.reshape(-1, 4)[:, 3] < 0).numpy(), err)
+    got = decode_match(D.merge_matches_by_position(recs))
     if got is None:
       return None
     return int(ref[got[0]]), got[1], got[2]

@@ -82,8 +82,9 @@ def infer_api(work):
                     report["mismatch"].append(["multiple", i])
         report["calls"] += 1
     counts = [None, None]
-    dist.all_gather_object(counts, len(sh.feature_volumes))
-    report["local_frames"] = counts
+    dist.all_gather_object(counts, [len(sh.feature_volumes), dict(sh.sharded_stats)])
+    report["local_frames"] = [c[0] for c in counts]
+    report["stats"] = [c[1] for c in counts]
     try:
         sh.infer_multiple(frames + 3, [0])           # out of order: refused in sharded mode
         report["order_error"] = False
@@ -98,6 +99,24 @@ def infer_api(work):
         ref.infer_multiple(0, [])
         b1 = ref.infer_multiple(1, [0])
         report["reset_ok"] = bool(a0 is None and np.array_equal(a1[0], b1[0]) and np.array_equal(a1[1], b1[1]) and a1[0].shape == ())
+    # a failure of ONE rank's local work (here: rank 1's leg raises) reaches every rank through the collective's payload: both
+    # raise, nobody is left waiting in the all-gather
+    if rank == 1:
+        def boom(names):
+            raise Exception("Could not read depth image (simulated, rank 1 only)")
+        sh._leg_device = boom
+    sh._stream_ahead = False
+    sh._drop_ahead()
+    raised = [None, None]
+    for k, call in enumerate((lambda: sh.infer_multiple(2, [0, 1]), lambda: sh.infer_best_match(3, [0, 1], 0.3))):
+        try:
+            call()
+            raised[k] = "returned"
+        except Exception as ex:
+            raised[k] = str(ex)[:80]
+    both = [None, None]
+    dist.all_gather_object(both, raised)
+    report["one_rank_failure"] = both
     sh.close()
     if ref is not None:
         ref.close()

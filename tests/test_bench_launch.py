@@ -39,3 +39,18 @@ def test_plain_invocation_spawns_ranks_and_reports_missing_gpus():
     assert "2 GPUs needed, %d visible (rank 0)" % vis in p.stderr
     assert "2 GPUs needed, %d visible (rank 1)" % vis in p.stderr
     assert p.stdout.strip() == ""          # stdout stays reserved for the ONE JSON line
+
+
+def test_rehearsal_without_a_gpu_says_so_on_every_rank():
+    """`--rehearsal` drops the one-GPU-per-rank requirement (all ranks share device 0) but still needs that one device."""
+    import torch
+    if torch.cuda.device_count() >= 1:
+        import pytest
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MASTER_PORT"] = str(29900 + os.getpid() % 90)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rehearsal", "--pool-total", "128", "--steps", "1",
+                        "--warmup", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "--rehearsal: needs one GPU, none visible (rank 0)" in p.stderr and "(rank 1)" in p.stderr
+    assert p.stdout.strip() == ""

@@ -1,7 +1,7 @@
 """GPU: two processes run the REAL kernels on their shards of one sweep (both on cuda:0, gloo rendezvous, host tensors in the
 collectives -- the box has one GPU; on a multi-GPU node the same code runs one rank per GPU over RCCL) and must reproduce the
 single-process results bit for bit: engine level (contiguous aligned blocks + one gather / one 16-byte record per rank) and through
-the drop-in `Infer(config, rank=, world=)` (block-cyclic ownership of a growing cache).  SURVEY.md 8e; reference API: infer.py:162-203."""
+the drop-in `Infer(config, rank=, world=)` (skewed block-cyclic ownership of a growing cache).  SURVEY.md 8e; reference API: infer.py:162-203."""
 import json
 import os
 import subprocess
@@ -68,6 +68,15 @@ def test_sharded_infer_equals_the_unsharded_object(tmp_path, fixture_npz):
     json.dump(cfg, open(tmp_path / "config.json", "w"))
     r = _run_two("infer_api", tmp_path)
     assert r["calls"] == frames and r["mismatch"] == [], r
-    assert r["local_frames"] == [38, 32]                              # frames 0-31 and 64-69 on rank 0, 32-63 on rank 1
+    # skewed block-cyclic ownership (distributed.frame_owner): even / odd frames alternate inside a block of 32 -> 35 frames each;
+    # the local caches' high-water slots: rank 0 holds frame 68 at slot 32 + 4, rank 1 frame 69 at slot 32 + 5
+    st = r["stats"]
+    assert [s["frames_cached"] for s in st] == [35, 35] and r["local_frames"] == [37, 38], r
+    # every scored pair went to the library on the rank's cache rows (feature volume + spectrum + Delta row), none through a
+    # replicated or per-pair fallback; the look-ahead computed a Delta row only for the frames the rank owns
+    assert all(s["pairs_scored"] > 500 and s["pairs_on_cache_rows"] == s["pairs_scored"] for s in st), st
+    assert all(0 < s["ahead_delta_rows"] <= s["frames_cached"] for s in st), st
+    f = r["one_rank_failure"]
+    assert all("rank(s) [1]" in m for m in f[0]) and all("simulated" in m for m in f[1]), f      # rank 0 / rank 1: both raise, both calls
     assert r["order_error"] is True and r["reset_ok"] is True
     assert len(r["best"]) == frames // 5 and any(b[0] is not None for b in r["best"])
