@@ -358,21 +358,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
-    if rehearsal:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)      # host tensors in the collectives (distributed._comm_device)
-        dist.barrier()
-    elif use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        # RCCL prints its version banner on STDOUT (C stdio, fully buffered when stdout is a pipe) at communicator creation; this
-        # program's stdout is ONE JSON line, so fd 1 points at stderr until the first collective has run and C stdio is flushed
+        # RCCL prints its version banner (and gloo its "[Gloo] Rank r is connected ..." lines) on STDOUT (C stdio, fully buffered when
+        # stdout is a pipe) at communicator creation; this program's stdout is ONE JSON line, so fd 1 points at stderr until the
+        # first collective has run and C stdio is flushed
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if rehearsal:     # all ranks on ONE device: host tensors in the collectives (distributed._comm_device)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
         finally:

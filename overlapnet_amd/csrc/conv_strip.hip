@@ -61,7 +61,6 @@ template <int CIN, int KH, int SH, int KW, int TW, int NT, int NW, int WPS>
 __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
   constexpr int ABUF = WPS >= 4 ? 1 : 2;
   typedef StripCfg<CIN, KH, KW, TW, NT, NW> C;
-  constexpr int NTHR = 64 * NW;
   static_assert(NW % NT == 0, "waves = n-tiles x groups of m-tiles");
   constexpr int COUT = 16 * NT;
   constexpr int PLANE = C::PLANE, PIX = C::PIX, MTH = C::MTH, CC = C::CC, NK = C::NK;
@@ -106,10 +105,21 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
   STRIP_LOAD_B(1, 1)
 
   // ---- strip -> LDS, split once ----
+  // Lane <-> element order of the staging: a wave instruction covers 8 consecutive strip pixels x 4 planes (32 channels = one
+  // 128-byte line per pixel); lane = (plane pg = lane / 16, pixel pl = (lane / 2) % 8, half h = lane % 2 of the plane's 8 channels).
+  // The 16 lanes a ds_write_b64 services together then write 128 CONTIGUOUS bytes of one plane (all 32 banks once).  With
+  // consecutive lanes on consecutive channel groups of one pixel (rounds 2-4) they hit 4 / 8 / 16 planes at the same bank offset --
+  // planes are a multiple of 256 B apart -- i.e. 4- / 8- / 16-way write conflicts (CIN 32 / 64 / 128) that held the LDS pipe the
+  // co-resident workgroups' fragment reads need: 9 / 39 / 24 % on top of the K loops' read cycles for s_conv3 / s_conv3a / s_conv4
+  // (profiles/r3_leg_pmc.md: conflict cycles 36-109 % of the LDS-active cycles).  Same values into the same slots: same bits.
   if (!(STRIP_ABL & 1)) {
-    constexpr int Q = CIN / 4;                                // float4 groups per pixel
-    constexpr int TOTAL = KH * PIX * Q;
-    constexpr int ITERS = (TOTAL + NTHR - 1) / NTHR;
+    constexpr int NQ = KH * PIX;                              // strip pixels (rows are consecutive in a plane)
+    constexpr int QG = (NQ + 7) / 8;                          // groups of 8 pixels
+    constexpr int PQ = C::NPL / 4;                            // quads of planes
+    constexpr int UNITS = QG * PQ;                            // wave instructions of the whole strip
+    constexpr int ITERS = (UNITS + NW - 1) / NW;
+    static_assert(C::NPL % 4 == 0, "planes are staged four at a time");
+    const int h4 = 4 * (lane & 1), pl = (lane >> 1) & 7, pg = lane >> 4;
     // all loads of a batch are issued before the first is consumed (a rolled loop would pay one memory round trip
     // per iteration: the compiler cannot overlap iterations it does not see)
     constexpr int BATCH = 6;
@@ -118,25 +128,23 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
       f32x4 v[BATCH];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int i = tid + (it0 + u) * NTHR;
+        const int unit = (it0 + u) * NW + wave;
+        const int qg = unit / PQ, pq = unit - qg * PQ;
+        const int q = 8 * qg + pl;
+        const int row = q / PIX, pix = q - row * PIX;
+        const int c = (4 * pq + pg) * 8 + h4;
         v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (i < TOTAL) {
-          const int row = i / (PIX * Q);
-          const int r = i - row * (PIX * Q);
-          const int pix = r / Q;
-          const int c = 4 * (r - pix * Q);
+        if (unit < UNITS && q < NQ) {
           if (STRIP_ABL & 4) v[u] = (f32x4){a.one, a.sw, a.one, a.sw};
           else if (pix < pixv) v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy + row) * a.W + x0 + pix) * CIN + c);
         }
       }
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int i = tid + (it0 + u) * NTHR;
-        if (i < TOTAL) {
-          const int row = i / (PIX * Q);
-          const int r = i - row * (PIX * Q);
-          const int pix = r / Q;
-          const int c = 4 * (r - pix * Q);
+        const int unit = (it0 + u) * NW + wave;
+        const int qg = unit / PQ, pq = unit - qg * PQ;
+        const int q = 8 * qg + pl;
+        if (unit < UNITS && q < NQ) {
           f16x4 h, l;
 #pragma unroll
           for (int e = 0; e < 4; e += 2) {
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
             l[e] = (_Float16)__builtin_fmaf(x0, one, -(float)hp[0]);
             l[e + 1] = (_Float16)__builtin_fmaf(x1, one, -(float)hp[1]);
           }
-          const int o = (c >> 3) * PLANE + (row * PIX + pix) * 8 + (c & 7);
+          const int o = (4 * pq + pg) * PLANE + q * 8 + h4;
           *reinterpret_cast<f16x4*>(sh + o) = h;
           *reinterpret_cast<f16x4*>(sl + o) = l;
         }
@@ -165,43 +173,78 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
 #pragma unroll
   for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  f16x8 fh[ABUF][MTH], fl[ABUF][MTH];
-#define STRIP_READ_A(BUF, KS)                                                      \
-  {                                                                                \
+  // WPS 3 (168 registers: three waves per SIMD, i.e. three 4-wave workgroups per CU): the lo fragments are single-buffered -- read
+  // at their own step, AHEAD of the next step's hi fragments (LDS returns in order), and first used after the step's MTH hi x hi MFMAs
+  constexpr int LBUF = (WPS == 3) ? 1 : ABUF;
+  f16x8 fh[ABUF][MTH], fl[LBUF][MTH];
+#define STRIP_TOFF(KS)                                                             \
     constexpr int tap_ = (KS) / CC;                                                \
     constexpr int ky_ = tap_ / KW;                                                 \
-    constexpr int toff_ = (ky_ * PIX + (tap_ - ky_ * KW)) * 8 + 4 * PLANE * ((KS) - tap_ * CC); \
-    _Pragma("unroll") for (int i = 0; i < MTH; ++i) {                              \
-      fh[BUF][i] = *reinterpret_cast<const f16x8*>(ah_base + toff_ + i * 128);    \
-      fl[BUF][i] = *reinterpret_cast<const f16x8*>(al_base + toff_ + i * 128);    \
-    }                                                                              \
+    constexpr int toff_ = (ky_ * PIX + (tap_ - ky_ * KW)) * 8 + 4 * PLANE * ((KS) - tap_ * CC);
+#define STRIP_READ_AH(BUF, KS, M)                                                  \
+  {                                                                                \
+    STRIP_TOFF(KS)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < (M); ++i) fh[BUF][i] = *reinterpret_cast<const f16x8*>(ah_base + toff_ + i * 128); \
   }
-#define STRIP_MFMA(BUF, SLOT)                                                                                  \
-  _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
+#define STRIP_READ_AL(BUF, KS, M)                                                  \
+  {                                                                                \
+    STRIP_TOFF(KS)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < (M); ++i) fl[BUF][i] = *reinterpret_cast<const f16x8*>(al_base + toff_ + i * 128); \
+  }
+#define STRIP_MFMA(BUF, LB, SLOT, M)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < (M); ++i)                                                              \
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
-  _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
-      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[BUF][i], bq[SLOT][0], acc[i], 0, 0, 0);             \
-  _Pragma("unroll") for (int i = 0; i < MTH; ++i)                                                              \
+  _Pragma("unroll") for (int i = 0; i < (M); ++i)                                                              \
+      acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[LB][i], bq[SLOT][0], acc[i], 0, 0, 0);              \
+  _Pragma("unroll") for (int i = 0; i < (M); ++i)                                                              \
       acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[BUF][i], bq[SLOT][1], acc[i], 0, 0, 0);
   __syncthreads();  // strip complete
-  if (ABUF == 2) STRIP_READ_A(0, 0)
-  // fully unrolled K walk (compile-time k): 3 weight slots x 2 fragment buffers, everything one step (A) / two steps (B) ahead
-  if (!(STRIP_ABL & 2)) [&]<int... K>(std::integer_sequence<int, K...>) {
-    (([&] {
-       if constexpr (K + 2 < NK) STRIP_LOAD_B((K + 2) % 3, K + 2)
-       if constexpr (ABUF == 2) {
-         if constexpr (K + 1 < NK) STRIP_READ_A((K + 1) & 1, K + 1)
-       } else {
-         STRIP_READ_A(0, K)
-       }
-       __builtin_amdgcn_sched_barrier(0);
-       STRIP_MFMA(K & (ABUF - 1), K % 3)
-       __builtin_amdgcn_sched_barrier(0);
-     }()),
-     ...);
-  }(std::make_integer_sequence<int, NK>{});
+  // fully unrolled K walk (compile-time k) over the first M m-tiles of the wave: 3 weight slots x 2 fragment buffers, everything one
+  // step (A) / two steps (B) ahead
+  auto kwalk = [&]<int M>(std::integral_constant<int, M>) {
+    if (ABUF == 2) {
+      STRIP_READ_AH(0, 0, M)
+      if (LBUF == 2) STRIP_READ_AL(0, 0, M)
+    }
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+      (([&] {
+         if constexpr (K + 2 < NK) STRIP_LOAD_B((K + 2) % 3, K + 2)
+         if constexpr (ABUF == 2 && LBUF == 2) {
+           if constexpr (K + 1 < NK) {
+             STRIP_READ_AH((K + 1) & 1, K + 1, M)
+             STRIP_READ_AL((K + 1) & 1, K + 1, M)
+           }
+         } else if constexpr (ABUF == 2) {
+           STRIP_READ_AL(0, K, M)
+           if constexpr (K + 1 < NK) STRIP_READ_AH((K + 1) & 1, K + 1, M)
+         } else {
+           STRIP_READ_AH(0, K, M)
+           STRIP_READ_AL(0, K, M)
+         }
+         __builtin_amdgcn_sched_barrier(0);
+         STRIP_MFMA(K & (ABUF - 1), K & (LBUF - 1), K % 3, M)
+         __builtin_amdgcn_sched_barrier(0);
+       }()),
+       ...);
+    }(std::make_integer_sequence<int, NK>{});
+  };
+  if (!(STRIP_ABL & 2)) {
+    if constexpr (C::MSPLIT == 1) {
+      // one wave per n-tile: the LAST tile of a row holds fewer m-tiles than the others (s_conv3: 112 + 112 + 112 + 79 pixels = 7 + 7 +
+      // 7 + 5 m-tiles, the 26 the row needs; s_conv3a: 6 x 4 + 2) -- its K walk is instantiated for that count instead of running the
+      // empty m-tiles (rounds 3-4: 28 per row, + 8 % / + 11 % issued MFMAs).  Same order per accumulator: same bits.
+      const int mw = (tw + 15) >> 4;   // workgroup-uniform
+      [&]<int... Ms>(std::integer_sequence<int, Ms...>) {
+        ((mw == MTH - Ms ? (kwalk(std::integral_constant<int, MTH - Ms>{}), 0) : 0), ...);
+      }(std::make_integer_sequence<int, MTH>{});
+    } else {
+      kwalk(std::integral_constant<int, MTH>{});
+    }
+  }
 #undef STRIP_LOAD_B
-#undef STRIP_READ_A
+#undef STRIP_TOFF
+#undef STRIP_READ_AH
+#undef STRIP_READ_AL
 #undef STRIP_MFMA
 
   // ---- epilogue: bias + ReLU.  C/D layout: lane holds output channel lrow of its n-tile, rows 4g..4g+3 of each m-tile
@@ -500,7 +543,7 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
     // the tile width does not change a bit; more workgroups, each with less to do)
     case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64:   // s_conv3
       rc = (nb <= SMALL_NB) ? launch_strip<32, 3, 2, 15, 52, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
-                            : launch_strip<32, 3, 2, 15, 104, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+                            : launch_strip<32, 3, 2, 15, 112, 4, 4, 3>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64:   // s_conv3a
       rc = (nb <= SMALL_NB) ? launch_strip<64, 3, 2, 12, 32, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
