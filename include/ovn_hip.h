@@ -39,7 +39,7 @@ typedef struct ovn_ctx ovn_ctx;
 #define OVN_ERR_STATE 3    /* call order (weights missing ...)  */
 
 /* ABI version of this header; bumped on any signature change. */
-#define OVN_ABI_VERSION 3
+#define OVN_ABI_VERSION 4
 int ovn_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -228,6 +228,14 @@ int ovn_set_head_precision(ovn_ctx* ctx, int mode);
 
 /* Arithmetic of the leg convolutions, same two modes as ovn_set_head_precision (default 1). */
 int ovn_set_leg_precision(ovn_ctx* ctx, int mode);
+
+/* Which float32 `np.arctan2` / `np.arcsin` (src/utils/utils.py:86-87) ovn_project / ovn_projection_angles reproduce:
+ *   0 (default)  NumPy >= 1.22 on an AVX512_SKX x86-64 host: Intel SVML's 1-4 ulp kernels, bit for bit (csrc/svml_f32.h) -- the
+ *                machine the reference's shipped .npy files and this repo's golden vectors were produced on;
+ *   1            the correctly rounded float32 results (float64 function, rounded once): what NumPy gives where its float32 loops
+ *                call a correctly rounded libm (AVX2-only x86, aarch64 ...).  The two differ in the last bit of 38 % of the angles
+ *                and put a point into the neighbouring pixel about once per 200 k points. */
+int ovn_set_projection_trig(ovn_ctx* ctx, int mode);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream, for bench.py's roofline line.
  * Between begin and end every kernel group launched through this context is bracketed by an event

@@ -669,7 +669,7 @@ int ovn_projection_angles(ovn_ctx* ctx, const float* points_dev, int64_t n_point
   OVN_REQUIRE(points_dev != nullptr, OVN_ERR_ARG, "ovn_projection_angles: points is NULL");
   OVN_ON_DEVICE(ctx->device);
   return ovn_projection_angles_forward(points_dev, n_points, proj_h, proj_w, fov_up_deg, fov_down_deg, max_range, yaw_dev,
-                                       pitch_dev, pixel_dev, (hipStream_t)stream);
+                                       pitch_dev, pixel_dev, (hipStream_t)stream, ctx->proj_trig);
 }
 
 int ovn_normals(ovn_ctx* ctx, const float* range_dev, const float* vertex_dev, int n_scans, int proj_h, int proj_w,
@@ -708,6 +708,13 @@ int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_precision: ctx is NULL");
   OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_head_precision: mode %d (0 = fp32 MFMA, 1 = f16x3 MFMA)", mode);
   ctx->head_mode = mode;
+  return OVN_OK;
+}
+
+int ovn_set_projection_trig(ovn_ctx* ctx, int mode) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_projection_trig: ctx is NULL");
+  OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_projection_trig: mode %d (0 = NumPy / SVML float32, 1 = correctly rounded)", mode);
+  ctx->proj_trig = mode;
   return OVN_OK;
 }
 

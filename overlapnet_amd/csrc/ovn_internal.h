@@ -161,6 +161,7 @@ struct ovn_ctx {
   float* w2sum = nullptr;  // c_conv2 kernel summed over its 15 taps, [64][128]: the right-volume linear term pushed through c_conv2
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
+  int proj_trig = 0;       // ovn_set_projection_trig: 0 = NumPy-on-AVX512 (SVML) float32 angles, 1 = correctly rounded float32 angles
   unsigned* actmax = nullptr;   // [layer][scan of the slice][OVN_ACTMAX_STRIDE] float bits of max |layer input| of that scan (f16x3 scales)
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = scaled 3-term fp16 split on the fp16 MFMA (default)
   float* wd = nullptr;   // dense kernel [123904]
@@ -307,7 +308,7 @@ int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offset
                         hipStream_t stream);
 
 int ovn_projection_angles_forward(const float* points, int64_t n, int H, int W, double fov_up_deg, double fov_down_deg,
-                                  double max_range, float* yaw, float* pitch, int32_t* pixel, hipStream_t stream);
+                                  double max_range, float* yaw, float* pitch, int32_t* pixel, hipStream_t stream, int trig = 0);
 int ovn_normals_forward(const float* range, const float* vertex, int n_scans, int H, int W, float* normal,
                         hipStream_t stream);
 

@@ -31,6 +31,8 @@ struct ProjGeom {
   float fov_down_abs;  // float32(|fov_down| in radians)
   float fov;           // float32(|fov_down| + |fov_up|)
   float max_range;
+  int trig;            // 0: NumPy's float32 arctan2 / arcsin on AVX512_SKX x86-64 (SVML, svml_f32.h); 1: the correctly rounded float32
+                       // results (float64 function rounded once) -- what a host whose NumPy calls a correctly rounded libm produces
 };
 
 // utils.py:75-104 for one point: depth, the range filter, both angles and the pixel.  false = dropped by the filter.
@@ -40,8 +42,13 @@ __device__ __forceinline__ bool point_to_pixel(float x, float y, float z, const 
   yaw = pitch = 0.f;
   pix = 0;
   if (!((depth > 0.0f) && (depth < gm.max_range))) return false;   // utils.py:76-77
-  yaw = -ovn_svml::atan2f_np(y, x);                            // utils.py:86  (np.arctan2 on float32: svml_f32.h)
-  pitch = ovn_svml::asinf_np(z / depth);                       // utils.py:87  (np.arcsin on float32)
+  if (gm.trig == 0) {
+    yaw = -ovn_svml::atan2f_np(y, x);                          // utils.py:86  (np.arctan2 on float32: svml_f32.h)
+    pitch = ovn_svml::asinf_np(z / depth);                     // utils.py:87  (np.arcsin on float32)
+  } else {                                                     // ovn_set_projection_trig(ctx, 1)
+    yaw = -(float)atan2((double)y, (double)x);
+    pitch = (float)asin((double)(z / depth));
+  }
   float px = 0.5f * (yaw / 3.14159274101257324f + 1.0f);       // utils.py:90
   float py = 1.0f - (pitch + gm.fov_down_abs) / gm.fov;        // utils.py:91
   px = px * (float)gm.W;                                       // utils.py:94
@@ -318,7 +325,7 @@ __global__ void proj_normal_kernel(const float* __restrict__ range, const float*
 }
 
 // same double arithmetic as utils.py:70-72, then the float32 casts NumPy applies to the scalars
-ProjGeom make_geom(int H, int W, double fov_up_deg, double fov_down_deg, double max_range) {
+ProjGeom make_geom(int H, int W, double fov_up_deg, double fov_down_deg, double max_range, int trig) {
   const double up = fov_up_deg / 180.0 * 3.14159265358979323846;
   const double down = fov_down_deg / 180.0 * 3.14159265358979323846;
   ProjGeom gm;
@@ -327,14 +334,15 @@ ProjGeom make_geom(int H, int W, double fov_up_deg, double fov_down_deg, double 
   gm.fov_down_abs = (float)fabs(down);
   gm.fov = (float)(fabs(down) + fabs(up));
   gm.max_range = (float)max_range;
+  gm.trig = trig;
   return gm;
 }
 
 }  // namespace
 
 int ovn_projection_angles_forward(const float* points, int64_t n, int H, int W, double fov_up_deg, double fov_down_deg,
-                                  double max_range, float* yaw, float* pitch, int32_t* pixel, hipStream_t stream) {
-  const ProjGeom gm = make_geom(H, W, fov_up_deg, fov_down_deg, max_range);
+                                  double max_range, float* yaw, float* pitch, int32_t* pixel, hipStream_t stream, int trig) {
+  const ProjGeom gm = make_geom(H, W, fov_up_deg, fov_down_deg, max_range, trig);
   const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
   hipLaunchKernelGGL(proj_angles_kernel, dim3(blocks), dim3(256), 0, stream, points, (long long)n, gm, yaw, pitch, pixel);
   OVN_HIP_CHECK(hipGetLastError());
@@ -351,7 +359,7 @@ int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offset
   const int C = (use_depth ? 1 : 0) + (use_normals ? 3 : 0) + (use_intensity ? 1 : 0);
   OVN_REQUIRE(!stacked || C > 0, OVN_ERR_ARG, "ovn_project: stacked output requested with no channel enabled");
 
-  const ProjGeom gm = make_geom(H, W, fov_up_deg, fov_down_deg, max_range);
+  const ProjGeom gm = make_geom(H, W, fov_up_deg, fov_down_deg, max_range, ctx->proj_trig);
 
   const long long HW = (long long)H * W;
   const long long npix = HW * n_scans;

@@ -46,6 +46,7 @@ class OvnEngine:
         self._head_ready = False
         self.head_precision = "f16x3"
         self.leg_precision = "f16x3"
+        self.projection_trig = "numpy_avx512"
         self.conv1size = 15
         self.check_device_indices = False    # opt-in range check of pair-index tensors that already live on the device (_idx)
 
@@ -434,6 +435,16 @@ class OvnEngine:
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
         self.head_precision = mode
 
+    def set_projection_trig(self, mode: str) -> None:
+        """Which float32 `np.arctan2` / `np.arcsin` (utils.py:86-87) `project` reproduces: 'numpy_avx512' (default: NumPy >= 1.22 on an
+        AVX512_SKX x86-64 host -- Intel SVML, bit for bit; the machine the reference's shipped .npy files were made on) or 'rounded'
+        (the correctly rounded float32 results: NumPy on hosts whose float32 loops call a correctly rounded libm)."""
+        table = {"numpy_avx512": 0, "rounded": 1}
+        if mode not in table:
+            raise ValueError("projection trig must be one of %s" % sorted(table))
+        _lib.check(self.lib.ovn_set_projection_trig(self._h, table[mode]), "ovn_set_projection_trig")
+        self.projection_trig = mode
+
     def set_leg_precision(self, mode: str) -> None:
         """Arithmetic of the leg convolutions: 'f16x3' (default, as above) or 'f32' (fp32 matrix cores)."""
         table = {"f32": 0, "f16x3": 1}
@@ -491,6 +502,7 @@ class QueryAhead:
         self.side.load_weights(weights, model_cfg)
         self.side.set_leg_precision(engine.leg_precision)
         self.side.set_head_precision(engine.head_precision)       # the spectrum kernel follows the head arithmetic
+        self.side.set_projection_trig(engine.projection_trig)     # (the look-ahead of Infer projects raw scans in this context)
         dev = engine.device
         with torch.cuda.device(dev):
             self.stream = torch.cuda.Stream(device=dev)
@@ -528,6 +540,8 @@ class QueryAhead:
             self.side.set_leg_precision(self.main.leg_precision)
         if self.side.head_precision != self.main.head_precision:
             self.side.set_head_precision(self.main.head_precision)
+        if self.side.projection_trig != self.main.projection_trig:
+            self.side.set_projection_trig(self.main.projection_trig)
         if wait_current:
             self.stream.wait_stream(torch.cuda.current_stream(self.main.device))   # the image belongs to the caller's stream
         if self._released[slot] is not None:

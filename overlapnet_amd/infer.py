@@ -17,7 +17,10 @@ types and error behaviour; the Keras/TensorFlow models behind it are replaced by
   * `config['scan_folder']` (extension key): read the RAW scans `<scan_folder>/<frame>.bin` and project them on the GPU
     (`ovn_project`: range image + normals + intensity straight into the stacked leg input) instead of reading demo1's `.npy`
     files -- demo1 + demo2/demo3 in one object (BASELINE configs[4]); same bits as the `.npy` route on files written by
-    `overlapnet_amd.preprocess`;
+    `overlapnet_amd.preprocess`.  The projection reproduces the reference's `utils.py` as it runs under NumPy >= 1.22 on an
+    AVX512_SKX x86-64 host (float32 `arctan2` / `arcsin` = Intel SVML, bit for bit); `config['projection_trig'] = 'rounded'`
+    selects the correctly rounded float32 angles instead (what NumPy's libm fallback gives on AVX2-only / aarch64 hosts: a point
+    moves to the neighbouring pixel about once per 200 k points);
   * `self.leg` / `self.head` are the native engine, not keras.Model objects.
 """
 from __future__ import annotations
@@ -187,6 +190,7 @@ class Infer():
     # sharded mode: what this rank did (tests assert that the cache-row path was taken, not a per-pair fallback)
     self.sharded_stats = {'frames_cached': 0, 'pairs_scored': 0, 'pairs_on_cache_rows': 0, 'ahead_delta_rows': 0}
     self._scan_folder = config.get('scan_folder') or None
+    self._projection_trig = config.get('projection_trig', 'numpy_avx512')     # extension key, with 'scan_folder' (engine.set_projection_trig)
     if self._scan_folder is not None and config['use_class_probabilities']:
       raise Exception("config['scan_folder']: the semantic channels come from RangeNet++ .npy files, not from the raw scans")
     self._stream_ahead = bool(config.get('stream_ahead', True))
@@ -251,6 +255,7 @@ class Infer():
       raise Exception("config['precision'] must be 'f16x3' or 'f32'")
     self.engine.set_leg_precision(self.precision)
     self.engine.set_head_precision(self.precision)
+    self.engine.set_projection_trig(self._projection_trig)
 
     # previous feature volumes (infer.py:114): list-like view of the HBM-resident cache
     self._feature_volumes = FeatureVolumeCache(self.engine)

@@ -446,6 +446,41 @@ def test_projection_angles_have_numpys_float32_bits(engines, fixture_npz):
             assert (np.abs(zz[keep] / depth[keep]) >= 0.5).sum() > 100000      # both arcsin branches
 
 
+def test_projection_trig_rounded_mode(engines, fixture_npz):
+    """`ovn_set_projection_trig(1)` (config['projection_trig'] = 'rounded'): the correctly rounded float32 arctan2 / arcsin -- the
+    reference's utils.py:86-87 as NumPy evaluates it where its float32 loops call a correctly rounded libm -- bit for bit against
+    float64 NumPy rounded once, the whole projection against the oracle in its 'f64' trig mode, and back to the default."""
+    from overlapnet_amd import preprocess as P
+    e = engines[4]
+    cloud = S.transformed_cloud(fixture_npz, 9)
+    dpts = torch.from_numpy(np.ascontiguousarray(cloud)).cuda()
+    yaw0, pitch0, _ = (t.cpu().numpy() for t in e.projection_angles(dpts))
+    e.set_projection_trig("rounded")
+    try:
+        yaw, pitch, pix = (t.cpu().numpy() for t in e.projection_angles(dpts))
+        x, y, z = (cloud[:, k].astype(np.float32) for k in range(3))
+        depth = np.sqrt((x * x + y * y) + z * z)
+        keep = (depth > 0) & (depth < np.float32(50.0))
+        assert np.array_equal(keep, pix >= 0)
+        o_yaw = (-np.arctan2(y[keep].astype(np.float64), x[keep].astype(np.float64))).astype(np.float32)
+        o_pitch = np.arcsin((z[keep] / depth[keep]).astype(np.float64)).astype(np.float32)
+        assert np.array_equal(yaw[keep].view(np.uint32), o_yaw.view(np.uint32))
+        assert np.array_equal(pitch[keep].view(np.uint32), o_pitch.view(np.uint32))
+        differs = float(np.mean(yaw[keep].view(np.uint32) != yaw0[keep].view(np.uint32)))
+        assert 0.1 < differs < 0.7            # the SVML kernels are 1-4 ulp functions: a third of the angles differ in the last bit
+        r = P.project_scans([cloud], engine=e, want=("range", "idx"))
+        o_rng, _, _, o_idx = O.range_projection(cloud, trig="f64")
+        assert np.array_equal(r["range"][0].cpu().numpy(), o_rng)
+        ties = r["idx"][0].cpu().numpy() != o_idx
+        assert ties.sum() <= 4                # (bit-identical depths in one pixel: the reference's unstable sort, see the test above)
+    finally:
+        e.set_projection_trig("numpy_avx512")
+    yaw1, _, _ = (t.cpu().numpy() for t in e.projection_angles(dpts))
+    assert np.array_equal(yaw1.view(np.uint32), yaw0.view(np.uint32))
+    with pytest.raises(ValueError):
+        e.set_projection_trig("libm")
+
+
 def test_projection_batch_ragged_and_edge_cases(engines, fixture_npz):
     from overlapnet_amd import preprocess as P
     p0, p1 = fixture_npz["points_0"], fixture_npz["points_1"]
