@@ -173,9 +173,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
 #pragma unroll
   for (int i = 0; i < MTH; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // WPS 3 (168 registers: three waves per SIMD, i.e. three 4-wave workgroups per CU): the lo fragments are single-buffered -- read
-  // at their own step, AHEAD of the next step's hi fragments (LDS returns in order), and first used after the step's MTH hi x hi MFMAs
-  constexpr int LBUF = (WPS == 3) ? 1 : ABUF;
+  constexpr int LBUF = ABUF;
   f16x8 fh[ABUF][MTH], fl[LBUF][MTH];
 #define STRIP_TOFF(KS)                                                             \
     constexpr int tap_ = (KS) / CC;                                                \
@@ -265,6 +263,202 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
     }
   }
   if (a.out_max) ovn_fold_absmax_wg(vmax, a.out_max + (size_t)b * OVN_ACTMAX_STRIDE, wg_red);   // wave-uniform condition: every thread calls it
+}
+
+// ---- batched calls: ROWS output rows per workgroup, NTW n-tiles per wave ------------------------------------------------------------
+// The chip runs these kernels AT ITS POWER CAP (tools/experiments/power_probe.py: 1.33 kW of 1.4 kW at 1.95 GHz under the batched
+// leg), so what a kernel costs is the energy of its MFMAs plus the energy of feeding them.  conv_strip_kernel above feeds 3 MFMAs per
+// pair of 1-KB LDS fragment reads (one n-tile per wave); the fused tail (2 n-tiles per wave) 6, the contraction kernel of the head 12.
+// Here a wave owns NTW n-tiles and ALL m-tiles of ONE of the workgroup's ROWS output rows (waves = NT / NTW x ROWS): an A pair feeds 3
+// NTW MFMAs, and no m-tile slot is padded (the earlier two-n-tiles-per-wave builds split the m-tiles of one row over wave groups and
+// lost to the padded slots, tools/experiments/README.md round 3).  Consecutive output rows share KH - SH input rows: the strip is
+// KH + SH (ROWS - 1) rows instead of KH ROWS.  Staging, scales and the per-accumulator order are those of conv_strip_kernel: same bits.
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NTW, int ROWS>
+struct Strip2Cfg {
+  static constexpr int PIX = TW + KW - 1;
+  static constexpr int KHS = KH + SH * (ROWS - 1);            // strip rows
+  static constexpr int PLANE = (KHS * PIX * 8 + 127) / 128 * 128;
+  static constexpr int NPL = CIN / 8;
+  static constexpr int MT = (TW + 15) / 16;
+  static constexpr int NG = NT / NTW;                         // wave groups along N
+  static constexpr int NW = NG * ROWS;
+  static constexpr int CC = CIN / 32;
+  static constexpr int NK = KH * KW * CC;
+  static constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 1024;
+  static_assert(NT % NTW == 0 && NPL % 4 == 0, "n-tiles per wave / planes staged four at a time");
+};
+
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NTW, int ROWS, int WPS>
+__global__ __launch_bounds__(64 * (NT / NTW) * ROWS, WPS) void conv_strip2_kernel(StripArgs a) {
+  typedef Strip2Cfg<CIN, KH, SH, KW, TW, NT, NTW, ROWS> C;
+  constexpr int NW = C::NW, NG = C::NG;
+  constexpr int COUT = 16 * NT;
+  constexpr int PLANE = C::PLANE, PIX = C::PIX, MT = C::MT, CC = C::CC, NK = C::NK, KHS = C::KHS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char strip_smem[];
+  __shared__ float wg_red[16];
+  _Float16* sh = reinterpret_cast<_Float16*>(strip_smem);
+  _Float16* sl = sh + C::NPL * PLANE;
+  const float one = a.one;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+  const int wq = wave % NG;    // group of NTW n-tiles
+  const int wr = wave / NG;    // output row of the block
+
+  int bid = blockIdx.x;
+  const int xt = bid % a.XT;
+  bid /= a.XT;
+  const int ohb = (a.OH + ROWS - 1) / ROWS;
+  const int oy0 = ROWS * (bid % ohb);
+  const int b = bid / ohb;
+  const int x0 = xt * TW;
+  const int tw = (a.OW - x0 < TW) ? a.OW - x0 : TW;
+  const int pixv = (a.W - x0 < PIX) ? a.W - x0 : PIX;
+  const float s_in = ovn_pow2_scale_for(__uint_as_float(a.in_max[(size_t)b * OVN_ACTMAX_STRIDE]));
+  const float inv = 1.0f / (s_in * a.sw);
+
+  const _Float16* wbase = a.wp + (size_t)__builtin_amdgcn_readfirstlane(wq * NTW) * (2 * 512) + lane * 8;
+  f16x8 bq[3][NTW][2];
+#define STRIP2_LOAD_B(SLOT, KS)                                                    \
+  {                                                                                \
+    const _Float16* q = wbase + (size_t)(KS) * (NT * 2 * 512);                      \
+    _Pragma("unroll") for (int j = 0; j < NTW; ++j) {                              \
+      bq[SLOT][j][0] = *reinterpret_cast<const f16x8*>(q + j * 1024);             \
+      bq[SLOT][j][1] = *reinterpret_cast<const f16x8*>(q + j * 1024 + 512);       \
+    }                                                                              \
+  }
+  STRIP2_LOAD_B(0, 0)
+  STRIP2_LOAD_B(1, 1)
+
+  // ---- strip -> LDS, split once (8 pixels x 4 planes per wave instruction, see conv_strip_kernel) ----
+  {
+    constexpr int NQ = KHS * PIX;
+    constexpr int QG = (NQ + 7) / 8;
+    constexpr int PQ = C::NPL / 4;
+    constexpr int UNITS = QG * PQ;
+    constexpr int ITERS = (UNITS + NW - 1) / NW;
+    const int h4 = 4 * (lane & 1), pl = (lane >> 1) & 7, pg = lane >> 4;
+    constexpr int BATCH = 6;
+#pragma unroll 1
+    for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+      f32x4 v[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int unit = (it0 + u) * NW + wave;
+        const int qg = unit / PQ, pq = unit - qg * PQ;
+        const int q = 8 * qg + pl;
+        const int row = q / PIX, pix = q - row * PIX;
+        const int c = (4 * pq + pg) * 8 + h4;
+        v[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (unit < UNITS && q < NQ && pix < pixv && SH * oy0 + row < a.H)
+          v[u] = *reinterpret_cast<const f32x4*>(a.in + (((long long)b * a.H + SH * oy0 + row) * a.W + x0 + pix) * CIN + c);
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int unit = (it0 + u) * NW + wave;
+        const int qg = unit / PQ, pq = unit - qg * PQ;
+        const int q = 8 * qg + pl;
+        if (unit < UNITS && q < NQ) {
+          f16x4 h, l;
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            const float x0f = v[u][e] * s_in, x1f = v[u][e + 1] * s_in;
+            const f16x2 hp = __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(x0f, x1f));
+            h[e] = hp[0];
+            h[e + 1] = hp[1];
+            l[e] = (_Float16)__builtin_fmaf(x0f, one, -(float)hp[0]);
+            l[e + 1] = (_Float16)__builtin_fmaf(x1f, one, -(float)hp[1]);
+          }
+          const int o = (4 * pq + pg) * PLANE + q * 8 + h4;
+          *reinterpret_cast<f16x4*>(sh + o) = h;
+          *reinterpret_cast<f16x4*>(sl + o) = l;
+        }
+      }
+    }
+  }
+
+  const _Float16* ah_base = sh + g * PLANE + (wr * SH * PIX + lrow) * 8;
+  const _Float16* al_base = sl + g * PLANE + (wr * SH * PIX + lrow) * 8;
+  f32x4 acc[MT][NTW];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f16x8 fh[2][MT], fl[1][MT];   // hi fragments one step ahead, lo fragments at their own step (ahead of the next step's hi reads)
+#define STRIP2_TOFF(KS)                                                            \
+    constexpr int tap_ = (KS) / CC;                                                \
+    constexpr int ky_ = tap_ / KW;                                                 \
+    constexpr int toff_ = (ky_ * PIX + (tap_ - ky_ * KW)) * 8 + 4 * PLANE * ((KS) - tap_ * CC);
+#define STRIP2_READ_AH(BUF, KS, M)                                                 \
+  {                                                                                \
+    STRIP2_TOFF(KS)                                                                \
+    _Pragma("unroll") for (int i = 0; i < (M); ++i) fh[BUF][i] = *reinterpret_cast<const f16x8*>(ah_base + toff_ + i * 128); \
+  }
+#define STRIP2_READ_AL(KS, M)                                                      \
+  {                                                                                \
+    STRIP2_TOFF(KS)                                                                \
+    _Pragma("unroll") for (int i = 0; i < (M); ++i) fl[0][i] = *reinterpret_cast<const f16x8*>(al_base + toff_ + i * 128); \
+  }
+  __syncthreads();  // strip complete
+  auto kwalk = [&]<int M>(std::integral_constant<int, M>) {
+    STRIP2_READ_AH(0, 0, M)
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+      (([&] {
+         if constexpr (K + 2 < NK) STRIP2_LOAD_B((K + 2) % 3, K + 2)
+         STRIP2_READ_AL(K, M)
+         if constexpr (K + 1 < NK) STRIP2_READ_AH((K + 1) & 1, K + 1, M)
+         __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+         for (int j = 0; j < NTW; ++j) {
+#pragma unroll
+           for (int i = 0; i < M; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[K & 1][i], bq[K % 3][j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+           for (int i = 0; i < M; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl[0][i], bq[K % 3][j][0], acc[i][j], 0, 0, 0);
+#pragma unroll
+           for (int i = 0; i < M; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh[K & 1][i], bq[K % 3][j][1], acc[i][j], 0, 0, 0);
+         }
+         __builtin_amdgcn_sched_barrier(0);
+       }()),
+       ...);
+    }(std::make_integer_sequence<int, NK>{});
+  };
+  {
+    const int mw = (tw + 15) >> 4;   // m-tiles this tile really holds (workgroup-uniform)
+    [&]<int... Ms>(std::integer_sequence<int, Ms...>) {
+      ((mw == MT - Ms ? (kwalk(std::integral_constant<int, MT - Ms>{}), 0) : 0), ...);
+    }(std::make_integer_sequence<int, MT>{});
+  }
+#undef STRIP2_LOAD_B
+#undef STRIP2_TOFF
+#undef STRIP2_READ_AH
+#undef STRIP2_READ_AL
+
+  // ---- epilogue: bias + ReLU; lane holds output channel lrow of each of its n-tiles, rows 4g..4g+3 of each m-tile
+  const int oy = oy0 + wr;
+  float vmax = 0.f;
+  if (oy < a.OH) {
+    float* orow = a.out + (((long long)b * a.OH + oy) * a.OW + x0) * COUT;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = 16 * (wq * NTW + j) + lrow;
+      const float bv = a.bias[n];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int p = 16 * i + 4 * g + r;
+          if (p < tw) {
+            const float v = fmaxf(fmaf(acc[i][j][r], inv, bv), 0.0f);
+            orow[(long long)p * COUT + n] = v;
+            vmax = fmaxf(vmax, v);
+          }
+        }
+      }
+    }
+  }
+  if (a.out_max) ovn_fold_absmax_wg(vmax, a.out_max + (size_t)b * OVN_ACTMAX_STRIDE, wg_red);   // kernel-uniform condition: every thread calls it
 }
 
 // ---- few input channels (s_conv1: 4, s_conv2: 16) --------------------------------------------------------------------------
@@ -500,6 +694,33 @@ int launch_strip(const OvnConvLayer& L, const float* in, int nb, long long call_
   return OVN_OK;
 }
 
+template <int CIN, int KH, int SH, int KW, int TW, int NT, int NTW, int ROWS, int WPS>
+int launch_strip2(const OvnConvLayer& L, const float* in, int nb, int h, int w, float* out, const unsigned* in_max, unsigned* out_max,
+                  hipStream_t stream, bool* took) {
+  typedef Strip2Cfg<CIN, KH, SH, KW, TW, NT, NTW, ROWS> C;
+  StripArgs a;
+  a.in = in;
+  a.wp = reinterpret_cast<const _Float16*>(L.wp_h);
+  a.bias = L.bias;
+  a.out = out;
+  a.in_max = in_max;
+  a.out_max = out_max;
+  a.sw = L.sw_h;
+  a.one = 1.0f;
+  a.H = h;
+  a.W = w;
+  a.OH = (h - KH) / SH + 1;
+  a.OW = w - KW + 1;
+  a.XT = (a.OW + TW - 1) / TW;
+  const long long wgs = (long long)nb * ((a.OH + ROWS - 1) / ROWS) * a.XT;
+  *took = true;
+  int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(conv_strip2_kernel<CIN, KH, SH, KW, TW, NT, NTW, ROWS, WPS>), C::LDS_BYTES);
+  if (rc) return rc;
+  hipLaunchKernelGGL((conv_strip2_kernel<CIN, KH, SH, KW, TW, NT, NTW, ROWS, WPS>), dim3((unsigned)wgs), dim3(64 * C::NW), C::LDS_BYTES, stream, a);
+  OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
 }  // namespace
 
 constexpr int SMALL_NB = 4;   // calls of at most this many scans take the narrow-tile instantiations below
@@ -536,26 +757,27 @@ int ovn_conv_strip_try(const OvnConvLayer& L, const float* in, int nb, long long
   if (L.kh > 1 && L.sh != 2) return 0;
   if (L.kh == 1 && L.sh != 1) return 0;
   switch (key) {
-    // s_conv3 / s_conv3a: workgroups of FOUR waves (one per n-tile, all m-tiles of a narrow tile each) -- three / two of them share a CU,
-    // so one stages or stores while another is in its K loop (the 8-wave, one-per-CU tiles of 208 / 135 pixels: +3 % leg time;
-    // same K order per accumulator, identical bits)
-    // (a call of a few scans -- the query of a loop-closure step -- takes narrower tiles: these kernels scale by the SCAN's maximum, so
-    // the tile width does not change a bit; more workgroups, each with less to do)
+    // s_conv3 / s_conv3a / s_conv4, batched calls: conv_strip2_kernel -- four waves, each TWO n-tiles and all m-tiles of one of the
+    // workgroup's output rows (an LDS fragment pair feeds 6 MFMAs instead of 3; the chip runs these kernels at its power cap, what
+    // counts is the energy per MFMA incl. its operand traffic): batched leg 4.70 -> 4.58 ms per 1025 scans on one box, same bits.
+    // A call of a few scans -- the query of a loop-closure step -- takes conv_strip_kernel with narrow tiles (one n-tile per wave,
+    // more workgroups, each with less to do): these kernels scale by the SCAN's maximum, so neither the tile width nor the kernel
+    // changes a bit
     case ((3 * 100 + 15) * 1000 + 32) * 1000 + 64:   // s_conv3
+      // 96-pixel tiles: 6 + 6 + 6 + 6 + 2 = the 26 m-tiles a 415-pixel row needs; two rows per workgroup share a 5-row strip (72 KB: two per CU)
       rc = (nb <= SMALL_NB) ? launch_strip<32, 3, 2, 15, 52, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
-                            : launch_strip<32, 3, 2, 15, 112, 4, 4, 3>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+                            : launch_strip2<32, 3, 2, 15, 96, 4, 2, 2, 2>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((3 * 100 + 12) * 1000 + 64) * 1000 + 64:   // s_conv3a
+      // 48-pixel tiles: 8 x 3 + 2 = the 26 m-tiles of a 404-pixel row; both output rows in one workgroup (5-row strip, 79 KB: two per CU)
       rc = (nb <= SMALL_NB) ? launch_strip<64, 3, 2, 12, 32, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
-                            : launch_strip<64, 3, 2, 12, 64, 4, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+                            : launch_strip2<64, 3, 2, 12, 48, 4, 2, 2, 2>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     // the 128-channel layers: tiles of 80 or 96 pixels (5 / 6 exact m-tiles), whichever wastes fewer padded rows of the row
     case ((2 * 100 + 9) * 1000 + 64) * 1000 + 128:    // s_conv4
-      // 128 registers per lane: two of these 45 KB workgroups per CU (with 144 registers only one fits; 1 % of the leg)
-      if (nb <= SMALL_NB) rc = launch_strip<64, 2, 2, 9, 32, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
-      else
-      rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<64, 2, 2, 9, 80, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
-                                                                 : launch_strip<64, 2, 2, 9, 96, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took);
+      // batched: four waves x two n-tiles, all 5 m-tiles of an 80-pixel tile each (396 = 5 x 80 - 4: 25 m-tiles, none padded)
+      rc = (nb <= SMALL_NB) ? launch_strip<64, 2, 2, 9, 32, 8, 8, 4>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
+                            : launch_strip2<64, 2, 2, 9, 80, 8, 2, 1, 2>(L, in, nb, h, w, out, in_max, out_max, stream, &took);
       break;
     case ((1 * 100 + 9) * 1000 + 128) * 1000 + 128:   // s_conv5-7
       rc = (pad_rows(w - 9 + 1, 80) <= pad_rows(w - 9 + 1, 96)) ? launch_strip<128, 1, 1, 9, 80, 8>(L, in, nb, call_nb, h, w, out, in_max, out_max, stream, &took)
