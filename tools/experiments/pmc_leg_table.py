@@ -3,7 +3,7 @@
 Only the 256-scan dispatches of a kernel are averaged (duration > half of the kernel's longest dispatch)."""
 import glob, os, sqlite3, sys
 
-KERNELS = ["leg_front", "conv_strip_kernelILi32E", "conv_strip_kernelILi64ELi3E", "conv_strip_kernelILi64ELi2E", "leg_tail"]   # mangled names: front, s_conv3, s_conv3a, s_conv4, tail
+KERNELS = ["leg_front", "conv_strip2_kernelILi32E", "conv_strip2_kernelILi64ELi3E", "conv_strip2_kernelILi64ELi2E", "leg_tail"]   # mangled names: front, s_conv3, s_conv3a, s_conv4 (batched: conv_strip2_kernel), tail
 agg = {}
 for d in sys.argv[1:]:
     for dbf in glob.glob(os.path.join(d, "*_results.db")):
