@@ -167,13 +167,15 @@ def rocprof_traffic(kernel_prefix: str, mode: str, extra_args):
 
 def cpu_baseline_preprocess(n_scans: int = 3):
     """the reference's NumPy preprocessing (`range_projection` + `gen_normal_map`, utils.py:59-186)
-    timed beside the HIP scatter, on this host.  kind 'port': the oracle's restatement (vectorised projection; the normal map is the
-    reference's per-pixel Python loop restated with array operations, so this baseline FLATTERS the CPU); kind 'reference': the
-    reference's own `utils.py` when OVERLAPNET_REFERENCE names a checkout of PRBonn/OverlapNet (never set on the bench box)."""
+    timed beside the HIP scatter, on this host, single thread as shipped.  kind 'port': the oracle's restatement in the reference's
+    STRUCTURE -- vectorised NumPy projection (utils.py:75-132 is vectorised too) and the per-pixel Python double loop of
+    `gen_normal_map` (utils.py:149-173; `oracle.gen_normal_map_literal`, bit-identical to the shipped normal images); the oracle's
+    vectorised normal map is reported next to it (`vectorised_scans_per_s`: what a NumPy user could have had).  kind 'reference':
+    the reference's own `utils.py` when OVERLAPNET_REFERENCE names a checkout of PRBonn/OverlapNet (never set on the bench box)."""
     from oracle import overlapnet_oracle as O
     fx = S.load_fixture_images()
     clouds = [S.fullstack_cloud(fx, i) for i in range(n_scans)]
-    kind, proj, normals = "port", O.range_projection, O.gen_normal_map
+    kind, proj, normals = "port", O.range_projection, O.gen_normal_map_literal
     ref_root = os.environ.get("OVERLAPNET_REFERENCE")
     if ref_root and os.path.isfile(os.path.join(ref_root, "src", "utils", "utils.py")):
         try:
@@ -192,9 +194,13 @@ def cpu_baseline_preprocess(n_scans: int = 3):
     t0 = time.perf_counter()
     normals(r[0], r[1])
     t_norm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.gen_normal_map(r[0], r[1])
+    t_vec = time.perf_counter() - t0
     return {"value": 1.0 / (t_proj + t_norm), "unit": "scans/s", "cores": 1, "kind": kind,
-            "sample": "%d KITTI-sized clouds through range_projection (%.4f s/scan) + one gen_normal_map (%.4f s/scan), single thread "
-                      "as shipped" % (len(clouds), t_proj, t_norm)}
+            "vectorised_scans_per_s": 1.0 / (t_proj + t_vec),
+            "sample": "%d KITTI-sized clouds through range_projection (%.4f s/scan) + ONE gen_normal_map as shipped, a per-pixel Python loop "
+                      "(%.3f s/scan; vectorised restatement %.4f s)" % (len(clouds), t_proj, t_norm, t_vec)}
 
 
 def cpu_baseline(channels: int, pool: int):

@@ -161,6 +161,35 @@ def gen_normal_map(current_range: np.ndarray, current_vertex: np.ndarray, proj_H
     return out
 
 
+def gen_normal_map_literal(current_range: np.ndarray, current_vertex: np.ndarray, proj_H: int = 64,
+                           proj_W: int = 900) -> np.ndarray:
+    """The normal image the way the reference computes it (`src/utils/utils.py:137-186`): one pixel at a time in a Python double
+    loop over columns and rows 0 .. H-2, NumPy calls on 3-vectors inside (`np.linalg.norm`, `np.cross`).  Cross-checks the
+    vectorised `gen_normal_map` (same values: `tests/test_oracle_preprocess.py`) and is what `bench.py` times as the CPU baseline of the
+    preprocessing stage "as shipped" (single thread, ~1 s per scan)."""
+    rng = np.asarray(current_range, F32)
+    vtx = np.asarray(current_vertex, F32)
+    out = np.full((proj_H, proj_W, 3), -1, F32)
+    for col in range(proj_W):
+        right = col + 1 if col + 1 < proj_W else col + 1 - proj_W          # `wrap`, utils.py:178-186
+        for row in range(proj_H - 1):                                      # the last row keeps -1 (utils.py:150)
+            if not rng[row, col] > 0:
+                continue
+            if not rng[row, right] > 0 or not rng[row + 1, col] > 0:
+                continue
+            here = vtx[row, col, :3]
+            to_right = vtx[row, right, :3] - here
+            to_lower = vtx[row + 1, col, :3] - here
+            with np.errstate(all="ignore"):
+                u_n = to_right / np.linalg.norm(to_right)
+                v_n = to_lower / np.linalg.norm(to_lower)
+                w = np.cross(v_n, u_n)                                     # utils.py:168
+                length = np.linalg.norm(w)
+            if length > 0:                                                 # NaN fails the test (utils.py:170)
+                out[row, col] = w / length
+    return out
+
+
 def stack_channels(depth: Optional[np.ndarray], normal: Optional[np.ndarray],
                    intensity: Optional[np.ndarray], probs: Optional[np.ndarray] = None) -> np.ndarray:
     """Channel stacking of one leg input, reference

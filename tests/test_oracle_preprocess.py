@@ -133,3 +133,13 @@ def test_other_geometries_match_the_reference(fixture_npz):
         if np.array_equal(idx, gi):
             assert _sha(inten) == str(g["geo_sha_intensity_%d" % k])
             assert _sha(O.gen_normal_map(rng, vtx, H, W)) == str(g["geo_sha_normal_%d" % k])
+
+
+def test_literal_normal_map_equals_the_vectorised_one_and_the_shipped_image(fixture_npz):
+    """`gen_normal_map_literal` (the reference's per-pixel double loop restated, what bench.py times as the CPU baseline of the
+    preprocessing stage) == the vectorised oracle == the reference's shipped `normal/000000.npy`, bit for bit."""
+    rng, vtx, _, _ = O.range_projection(fixture_npz["points_0"])
+    lit = O.gen_normal_map_literal(rng, vtx)
+    assert np.array_equal(lit, O.gen_normal_map(rng, vtx))
+    assert np.array_equal(lit, fixture_npz["normal_0"])
+
