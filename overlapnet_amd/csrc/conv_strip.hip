@@ -13,6 +13,9 @@
 // CIN/32 steps of 32 channels, exactly the chunk order of the pre-split weights [kc][nt][hi,lo][lane][8]).  NW (8 or 4) waves = NT
 // n-tiles x NW/NT groups of m-tiles; weight fragments straight from L2 three steps deep; A fragments for step s+1 are read
 // while step s feeds the matrix pipe.  Same per-accumulator summation order as the generic kernel: bit-identical results.
+// Kernels in this file: conv_strip_kernel (one n-tile per wave; calls of a few scans and the 1 x KW layers of non-standard nets),
+// conv_strip2_kernel (two n-tiles per wave, ROWS output rows per workgroup: batched s_conv3 / s_conv3a / s_conv4),
+// conv_strip_small_kernel (CIN 4 / 16: s_conv1 / s_conv2 when the fused front kernel does not apply).
 #include <stdlib.h>
 
 #include <utility>
@@ -228,9 +231,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void conv_strip_kernel(StripArgs a) {
   };
   if (!(STRIP_ABL & 2)) {
     if constexpr (C::MSPLIT == 1) {
-      // one wave per n-tile: the LAST tile of a row holds fewer m-tiles than the others (s_conv3: 112 + 112 + 112 + 79 pixels = 7 + 7 +
-      // 7 + 5 m-tiles, the 26 the row needs; s_conv3a: 6 x 4 + 2) -- its K walk is instantiated for that count instead of running the
-      // empty m-tiles (rounds 3-4: 28 per row, + 8 % / + 11 % issued MFMAs).  Same order per accumulator: same bits.
+      // one wave per n-tile: the LAST tile of a row holds fewer m-tiles than the others -- its K walk is instantiated for that count
+      // instead of running empty m-tiles (rounds 3-4 ran 28 m-tiles per s_conv3 / s_conv3a row where 26 are needed: + 8 % / + 11 %
+      // issued MFMAs; batched calls now take conv_strip2_kernel below, this serves the narrow tiles of calls of a few scans).  Same
+      // order per accumulator: same bits.
       const int mw = (tw + 15) >> 4;   // workgroup-uniform
       [&]<int... Ms>(std::integer_sequence<int, Ms...>) {
         ((mw == MTH - Ms ? (kwalk(std::integral_constant<int, MTH - Ms>{}), 0) : 0), ...);
