@@ -58,6 +58,8 @@ SPEC_BYTES_PER_PAIR = 188_416 + 4           # what the spectral form streams: on
 LEG_FLOP_PER_SCAN = {1: 1637.5e6, 4: 1733.2e6, 5: 1765.1e6}
 PEAK_F32_MFMA_TFLOPS = 157.3                # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
 PEAK_16BIT_MFMA_TFLOPS = 2500.0             # MI355X_MICROARCH.md: dense bf16/fp16 MFMA peak (not the 2:1-sparse figure)
+SUSTAINED_16BIT_MFMA_TFLOPS = 1850.0        # what a BARE fp16 MFMA loop on random register operands sustains on this chip (power management
+                                            # holds it at 2.09 GHz; 2272 TF on all-zero operands): profiles/r5_mfma_power.txt, tools/experiments/mfma_power.hip
 PEAK_HBM_BPS = 8.0e12
 
 HEAD_KERNEL = {
@@ -836,6 +838,9 @@ def main():
     rl0 = out["roofline"]
     rl0["traffic"] = t_bytes
     rl = {k: rl0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frac_executed")}
+    if args.head_precision == "f16x3":
+        # executed MFMA rate against what a bare MFMA loop sustains on real operands (a committed measurement, not this run's)
+        rl["executed_frac_of_sustained_mfma_rate"] = 3 * rl0["achieved"] / SUSTAINED_16BIT_MFMA_TFLOPS
     rl["traffic_from"] = (t_src.get("source") or "none") if isinstance(t_src, dict) else str(t_src)
     rl["step_pairs_per_s"] = out["value"]
 
@@ -862,9 +867,9 @@ def main():
             rl["latency_n1_ms"] = rec["ms_per_query"]
         if "ms_per_query_streamed" in rec:
             rl["latency_n1_streamed_ms"] = rec["ms_per_query_streamed"]
-    sub("warm_serial", "value", "warm_serial_pairs_per_s")
     sub("fp32_mode", "value", "fp32_mode_pairs_per_s")
     # ---- (beyond the driver's 24 keys: kept in the line itself) ----
+    sub("warm_serial", "value", "warm_serial_pairs_per_s")
     if "yaw_exact_rate" in out:
         rl["yaw_exact_rate"] = out["yaw_exact_rate"]
     if "infer_api" in out:
