@@ -269,8 +269,8 @@ constexpr size_t PREP_SPLIT_LDS = 2 * (size_t)G * TT_STRIDE * sizeof(_Float16) +
 // Where the contraction and c_conv2 kernels find a pair's operands: the per-pair scratch filled by the prepare kernel, or -- for a
 // sweep over candidates with a Delta cache (ovn_delta_cache) -- the candidate's cached row and the query's shared operands.
 struct DeltaDesc {
-  const unsigned* pl;   // packed L words [s(4)][i(360)][g(4)][8]
-  const unsigned* pr;   // packed R words [jb(24)][s(4)][dj(15)][g(4)][8]
+  const unsigned* pl;   // packed L words, channel-major [c(128)][i(360)]
+  const unsigned* pr;   // packed R words [jb(24)][sc(4)][dj(15)][g(4)][8] in the order of the pair's (compacted) K walk
   const float* tt;      // TT + b2 [24][128]
   const float* aa;      // AA [24][128]
 };
@@ -285,6 +285,80 @@ static_assert(DC_META + 4 <= OVN_DELTA_CACHE_ELEMS, "Delta cache row too small")
 constexpr int QV = 8;                                // packed versions of the query: scales sa_q, sa_q / 2, ... sa_q / 128
 // per-query operands shared by every cached pair of a sweep: [QV][46080] packed words | AA [24][128] | {max R, min R, 0, 0}
 constexpr size_t QBLOCK_WORDS = (size_t)QV * OVN_FEAT_ELEMS + G * O2 + 4;
+
+// ---- dead-channel compaction of a query (round 5) ---------------------------------------------------------------------------------
+// min(l', r') = 0 for EVERY candidate row wherever the query's word r'[j][c] is 0, and a feature channel that is 0 in all 360 columns
+// of the query (a quarter of the 128 channels under the benchmark's weights: ReLU outputs) drops out of the contraction altogether --
+// for every column group, every tap and every candidate of the sweep.  The K walk then covers ns < 4 slices of 32 LIVE channels
+// (dead ones pad the last slice): W1 fragments gathered once per query for those channels, the query's words packed in the same
+// order, and the candidates' L words -- stored CHANNEL-MAJOR ([c][360], in cache rows and scratch alike) -- fetched by the same list.
+// Exact (the dropped products are exact zeros); only the grouping of K into MFMA steps changes.  The list keeps the live channels in
+// the order of the uncompacted walk (slice s, lane group g, element e <-> channel 32 g + 8 s + e), so a query without dead channels
+// -- and any pair that needs a shift (negative values: r' = r + c has no zeros) -- walks exactly the K of rounds 2-4.
+constexpr int LIVE_WORDS = 4 + FC / 4;     // {ns, live channels, 0, 0} + 128 channel bytes: position 32 s + 8 g + e of the compacted walk
+__device__ __forceinline__ int ident_chan(int pos) { return 32 * ((pos >> 3) & 3) + 8 * (pos >> 5) + (pos & 7); }
+__device__ __forceinline__ unsigned ident_chan_word(int w) {
+  return (unsigned)ident_chan(4 * w) | (unsigned)ident_chan(4 * w + 1) << 8 | (unsigned)ident_chan(4 * w + 2) << 16 | (unsigned)ident_chan(4 * w + 3) << 24;
+}
+// channel table of a workgroup -> LDS (`use`: workgroup-uniform); returns the number of slices.  Caller synchronises.
+__device__ __forceinline__ int load_chan_table(const unsigned* __restrict__ live, bool use, unsigned char* chan_s, int tid) {
+  if (tid < FC / 4) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : ident_chan_word(tid);
+  return use ? (int)live[0] : 4;
+}
+
+// One workgroup per query: which channels are alive, in walk order; identity when the volume has a negative value.
+__global__ __launch_bounds__(512) void delta_live_kernel(const float* __restrict__ feats_r, unsigned* __restrict__ live) {
+  __shared__ int alive[4][FC];
+  __shared__ int neg_s;
+  __shared__ unsigned char chan_s[FC];
+  const int tid = threadIdx.x, c = tid & (FC - 1), part = tid >> 7;
+  if (tid == 0) neg_s = 0;
+  int any = 0, ng = 0;
+  for (int j = part; j < FW; j += 4) {
+    const float v = feats_r[(size_t)j * FC + c];
+    any |= (v != 0.0f);
+    ng |= (v < 0.0f);
+  }
+  alive[part][c] = any;
+  __syncthreads();
+  if (ng) atomicOr(&neg_s, 1);
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    const bool shifted = neg_s != 0;
+    for (int pos = 0; pos < FC; ++pos) {          // live channels first, in walk order
+      const int ch = ident_chan(pos);
+      if (shifted || (alive[0][ch] | alive[1][ch] | alive[2][ch] | alive[3][ch])) chan_s[n++] = (unsigned char)ch;
+    }
+    const int nlive = n;
+    for (int pos = 0; pos < FC && n < FC; ++pos) {  // dead ones behind them (they pad the last slice, exact zeros)
+      const int ch = ident_chan(pos);
+      if (!(shifted || (alive[0][ch] | alive[1][ch] | alive[2][ch] | alive[3][ch]))) chan_s[n++] = (unsigned char)ch;
+    }
+    int ns = (nlive + 31) / 32;
+    live[0] = (unsigned)(ns < 1 ? 1 : ns);
+    live[1] = (unsigned)nlive;
+    live[2] = live[3] = 0u;
+  }
+  __syncthreads();
+  if (tid < FC / 4) live[4 + tid] = reinterpret_cast<const unsigned*>(chan_s)[tid];
+}
+
+// W1 fragments of the compacted walk: out[sc][dj][nt][hi,lo][lane][e] = w1p[...] of channel chan[32 sc + 8 (lane >> 4) + e]
+__global__ __launch_bounds__(256) void delta_w1c_kernel(const _Float16* __restrict__ w1p, const unsigned* __restrict__ live,
+                                                        _Float16* __restrict__ w1c) {
+  const int ns = (int)live[0];
+  const unsigned char* chan = reinterpret_cast<const unsigned char*>(live + 4);
+  const int total = ns * S * 4 * 2 * 512;
+  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+    const int e = idx & 7, lane = (idx >> 3) & 63, hl = (idx >> 9) & 1, nt = (idx >> 10) & 3;
+    const int step = idx >> 12;                   // sc * 15 + dj
+    const int sc = step / S, dj = step - sc * S;
+    const int ch = chan[32 * sc + 8 * (lane >> 4) + e];
+    const int src_step = ((ch & 31) >> 3) * S + dj;
+    w1c[idx] = w1p[((((size_t)src_step * 4 + nt) * 2 + hl) * 64 + (lane & 15) + 16 * (ch >> 5)) * 8 + (ch & 7)];
+  }
+}
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
   // LDS-DMA: lane l's 16 bytes land at lds_wave_base + 16 l (the base is wave-uniform: it goes through M0)
@@ -315,8 +389,9 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const float* __restrict__ w2sum, const float* __restrict__ b2, float sw1, float sw2, float sws, float w1_colsum, float b1_absmax,
     float one, f32x4* __restrict__ scales, unsigned* __restrict__ o2max, unsigned* __restrict__ pl, unsigned* __restrict__ pr,
     float* __restrict__ lin, DeltaDesc* __restrict__ desc, const float* __restrict__ dcache, const unsigned* __restrict__ qblock,
-    float* __restrict__ cache_out) {
+    float* __restrict__ cache_out, const unsigned* __restrict__ live) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  __shared__ __attribute__((aligned(16))) unsigned char chan_p[FC];
   // T image, scaled fp16 hi / lo: T[15 ib + di][o] at [ib][di * 64 + 4 (o & 15) + (o >> 4)] (the K order of W2p)
   _Float16* Th = reinterpret_cast<_Float16*>(psm);
   _Float16* Tlo = Th + G * TT_STRIDE;
@@ -459,7 +534,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
       *reinterpret_cast<f32x4*>(crow + DC_META) = (f32x4){mx, mn, 0.f, 0.f};
     } else {
       scales[2 * pair] = (f32x4){sa, -2.0f * s1r / (sa * sw1), s1r, 1.0f / (s1r * sw2)};
-      scales[2 * pair + 1] = (f32x4){csa, c, span, 0.f};
+      scales[2 * pair + 1] = (f32x4){csa, c, span, (c == 0.0f) ? 1.f : 0.f};   // [3]: no shift -> the query's compacted K walk applies
       o2max[pair] = 0u;
       DeltaDesc d;
       d.pl = pl + (size_t)pair * OVN_FEAT_ELEMS;
@@ -478,32 +553,33 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const int i = tid + 512 * u;
     A2l[i] = v + c * w1col[i & (O1 - 1)];
   }
-  // R words in pass order (second read of R: L2 hits, all loads of a batch in flight)
+  // R words in the order of the pair's K walk (second read of R: L2 hits): the query's compacted channel list when the pair has no
+  // shift (1-vs-N sweeps; `live` is NULL for indexed pairs), the plain slice order otherwise
   if (!BUILD) {
+    const bool compact = live != nullptr && c == 0.0f;
+    const int ns = load_chan_table(live, compact, chan_p, tid);
+    __syncthreads();
     unsigned* Pr = pr + (size_t)pair * OVN_FEAT_ELEMS;
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      f32x4 rv[6][2];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int i8 = tid + 512 * (6 * half + k);
-        if (i8 < R_ITEMS) {
-          rv[k][0] = R4[2 * i8];
-          rv[k][1] = R4[2 * i8 + 1];
-        } else {
-          rv[k][0] = rv[k][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-      }
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-        const int i8 = tid + 512 * (6 * half + k);
-        if (i8 < R_ITEMS) {
-          const int jrow = i8 >> 4, ch = (i8 & 15) * 8;
+#pragma unroll 2
+    for (int k = 0; k < 12; ++k) {
+      const int i8 = tid + 512 * k;
+      if (i8 < R_ITEMS) {
+        const int jrow = i8 >> 4, sc = (i8 >> 2) & 3, gq = i8 & 3;
+        if (sc < ns) {
           const int jb = jrow / S, dj = jrow - jb * S;
-          const int gm = ch >> 5, s = (ch & 31) >> 3;
-          unsigned* dst = Pr + ((jb * 4 + s) * S + dj) * 32 + gm * 8;
-          *reinterpret_cast<u32x4*>(dst) = pack4(rv[k][0], sa, csa);
-          *reinterpret_cast<u32x4*>(dst + 4) = pack4(rv[k][1], sa, csa);
+          const float* rrow = Rf + (size_t)jrow * FC;
+          const unsigned char* ch = chan_p + 32 * sc + 8 * gq;
+          f32x4 v0, v1;
+          if (!compact) {   // 8 consecutive channels 32 gq + 8 sc ..
+            v0 = *reinterpret_cast<const f32x4*>(rrow + 32 * gq + 8 * sc);
+            v1 = *reinterpret_cast<const f32x4*>(rrow + 32 * gq + 8 * sc + 4);
+          } else {
+            v0 = (f32x4){rrow[ch[0]], rrow[ch[1]], rrow[ch[2]], rrow[ch[3]]};
+            v1 = (f32x4){rrow[ch[4]], rrow[ch[5]], rrow[ch[6]], rrow[ch[7]]};
+          }
+          unsigned* dst = Pr + ((jb * 4 + sc) * S + dj) * 32 + gq * 8;
+          *reinterpret_cast<u32x4*>(dst) = pack4(v0, sa, csa);
+          *reinterpret_cast<u32x4*>(dst + 4) = pack4(v1, sa, csa);
         }
       }
     }
@@ -525,9 +601,12 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
       if (i < FW) {
         w0 = pack4(lv[t][ks][0], sa, csa);
         w1 = pack4(lv[t][ks][1], sa, csa);
-        unsigned* dst = P + ((size_t)(g * FW + i) * 4 + ks) * 8;
-        *reinterpret_cast<u32x4*>(dst) = w0;
-        *reinterpret_cast<u32x4*>(dst + 4) = w1;
+        unsigned* dst = P + (size_t)(32 * ks + 8 * g) * FW + i;   // channel-major: channels 32 ks + 8 g .. + 7 of row i
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          dst[(size_t)e * FW] = w0[e];
+          dst[(size_t)(4 + e) * FW] = w1[e];
+        }
       } else {
         w0 = w1 = (u32x4){0u, 0u, 0u, 0u};
       }
@@ -635,9 +714,11 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
 // candidate whose own scale is that much coarser pairs with); workgroup 0 also leaves AA = (R W1) W2s and {max R, min R}.
 // Same arithmetic, in the same order, as the R / AA parts of delta_prepare_split_kernel with shift c = 0.
 __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restrict__ feats_r, const float* __restrict__ a2raw,
-                                                          const float* __restrict__ w2sum, unsigned* __restrict__ qblock) {
+                                                          const float* __restrict__ w2sum, unsigned* __restrict__ qblock,
+                                                          const unsigned* __restrict__ live) {
   __shared__ float red[2 * NWAVE];
   __shared__ float A2l[G * O1];
+  __shared__ __attribute__((aligned(16))) unsigned char chan_q[FC];
   const int ver = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4* R4 = reinterpret_cast<const f32x4*>(feats_r);
@@ -680,16 +761,25 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
   }
   const float sa = ldexpf(ovn_pow2_scale_for(mx), -ver);
   unsigned* Pr = qblock + (size_t)ver * OVN_FEAT_ELEMS;
-#pragma unroll
+  // the words in the order of the query's compacted K walk (`live`; a volume with a negative value has the identity list there, and
+  // no cached pair uses it anyway)
+  const int ns = load_chan_table(live, live != nullptr, chan_q, tid);
+  __syncthreads();
+#pragma unroll 2
   for (int k = 0; k < 12; ++k) {
     const int i8 = tid + 512 * k;
     if (i8 < R_ITEMS) {
-      const int jrow = i8 >> 4, ch = (i8 & 15) * 8;
-      const int jb = jrow / S, dj = jrow - jb * S;
-      const int gm = ch >> 5, sl = (ch & 31) >> 3;
-      unsigned* dst = Pr + ((jb * 4 + sl) * S + dj) * 32 + gm * 8;
-      *reinterpret_cast<u32x4*>(dst) = pack4(rv[k][0], sa, 0.0f);
-      *reinterpret_cast<u32x4*>(dst + 4) = pack4(rv[k][1], sa, 0.0f);
+      const int jrow = i8 >> 4, sc = (i8 >> 2) & 3, gq = i8 & 3;
+      if (sc < ns) {
+        const int jb = jrow / S, dj = jrow - jb * S;
+        const float* rrow = feats_r + (size_t)jrow * FC;
+        const unsigned char* ch = chan_q + 32 * sc + 8 * gq;
+        const f32x4 v0 = {rrow[ch[0]], rrow[ch[1]], rrow[ch[2]], rrow[ch[3]]};
+        const f32x4 v1 = {rrow[ch[4]], rrow[ch[5]], rrow[ch[6]], rrow[ch[7]]};
+        unsigned* dst = Pr + ((jb * 4 + sc) * S + dj) * 32 + gq * 8;
+        *reinterpret_cast<u32x4*>(dst) = pack4(v0, sa, 0.0f);
+        *reinterpret_cast<u32x4*>(dst + 4) = pack4(v1, sa, 0.0f);
+      }
     }
   }
   if (ver != 0) return;
@@ -743,10 +833,11 @@ template <int SPC, int ABL = 0, int JBP = 2>
 __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __restrict__ desc,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
                                                              float* __restrict__ o1raw, int rot, int nsplit, int pair0,
-                                                             const int32_t* __restrict__ lidx) {
+                                                             const int32_t* __restrict__ lidx, const unsigned* __restrict__ live,
+                                                             const _Float16* __restrict__ w1c) {
   constexpr int CHB = SPC * STEP_BYTES;          // window chunk
   constexpr int CPS = S / SPC;                   // chunks per channel slice
-  constexpr int NCH = 4 * CPS;                   // chunks per walk of K
+  __shared__ __attribute__((aligned(16))) unsigned char chan_s[FC];   // channel of position 32 sc + 8 g + e of this pair's K walk
   constexpr int PFN = CHB / (512 * 16);          // DMA instructions per lane per chunk
   static_assert(S % SPC == 0 && CHB % (512 * 16) == 0 && CPS >= 3, "bad chunking");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -765,21 +856,29 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   const unsigned* L = desc[pair].pl;     // per-pair scratch, or the candidate's cache row / the query's shared words
   const unsigned* Rw = desc[pair].pr;
   const float krow = scales[2 * pair][1];
-  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(w1p);
+  // the K walk of this pair: the query's compacted channel list (ns slices of 32 live channels, W1 fragments gathered for them) when
+  // the pair has no shift, the plain one (4 slices, the resident W1 fragments) otherwise -- workgroup-uniform
+  const bool compact = live != nullptr && scales[2 * pair + 1][3] != 0.0f;
+  const int ns = __builtin_amdgcn_readfirstlane(load_chan_table(live, compact, chan_s, tid));
+  const int NCH = ns * CPS;                      // chunks per walk of K
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(compact ? w1c : w1p);
   unsigned char* lmine = lst + wave * LST_WAVE_BYTES;
+  __syncthreads();   // channel table
 
-  // lane's L source of tile t (rows past the volume re-read row 359: their accumulators are never stored)
-  int lsrc[3];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    int i = 48 * wave + 16 * t + lrow;
-    i = i < FW ? i : FW - 1;
-    lsrc[t] = (i * 4 + g) * 8;
-  }
+  // The wave's L slice in LDS: [channel position 0..31][row 0..47] words (6 KB).  DMA instruction q moves words 256 q + 4 lane .. + 3
+  // = rows r .. r + 3 of position cl: 16 contiguous bytes of the channel-major volume.  (Rows past the volume -- wave 7, r >= 24 --
+  // read into the next channel's rows: their accumulators are never stored.)
+  // (the six (position, row) pairs of a lane are recomputed at every slice -- a handful of integer instructions per 30 MFMA steps --
+  // instead of living in six registers of a kernel that has none to spare: the opaque copy keeps the compiler from hoisting them)
 #define OVN_DMA_L(SL)                                                                            \
-  _Pragma("unroll") for (int t = 0; t < 3; ++t) {                                                \
-    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t], lmine + (2 * t) * 1024);              \
-    glds16(L + (size_t)(SL) * (FW * 32) + lsrc[t] + 4, lmine + (2 * t + 1) * 1024);      \
+  {                                                                                              \
+    int lane_o = lane;                                                                           \
+    asm volatile("" : "+v"(lane_o));                                                             \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                              \
+      const int o = (q * 64 + lane_o) * 4;                                                       \
+      const int cl = o / 48, r = o - 48 * cl;                                                    \
+      glds16(L + (size_t)chan_s[(SL) * 32 + cl] * FW + 48 * wave + r, lmine + q * 1024);         \
+    }                                                                                            \
   }
 #define OVN_DMA_W(CH, BUF)                                                                       \
   _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                \
@@ -797,7 +896,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   // result, depends neither on how the sweep is cut into launches nor on where the candidate stands in an index list -- a shard
   // of a pool whose first slot is a multiple of 32 (overlapnet_amd.distributed) reproduces the bits of the unsharded sweep
   const int slot = lidx ? lidx[pair] : pair0 + pair;
-  const int s0 = rot ? ((slot >> 3) & 3) : 0;
+  const int s0 = rot ? ((slot >> 3) & 3) % ns : 0;
   const int p_begin = part * (G / JBP) / nsplit, p_end = (part + 1) * (G / JBP) / nsplit;
   int cur = 0, rcur = 0;
   int chunk = CPS * s0;
@@ -817,21 +916,25 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
         for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const unsigned* rb = rbuf + rcur * R_PASS_WORDS + 8 * g;
 #pragma unroll 1
-    for (int q4 = 0; q4 < 4; ++q4) {
-      const int sl = (s0 + q4) & 3;
+    for (int q4 = 0; q4 < ns; ++q4) {
+      const int sl = (s0 + q4 >= ns) ? s0 + q4 - ns : s0 + q4;
       if (!(ABL & 8) || (pass == p_begin && q4 == 0)) {
+        // this lane's 8 words of each row tile: positions 8 g .. 8 g + 7 of the slice, row 16 t + lrow of the wave's 48
+        const unsigned* lw = reinterpret_cast<const unsigned*>(lmine) + (8 * g) * 48 + lrow;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-          la[t][0] = *reinterpret_cast<const u32x4*>(lmine + (2 * t) * 1024 + lane * 16);
-          la[t][1] = *reinterpret_cast<const u32x4*>(lmine + (2 * t + 1) * 1024 + lane * 16);
-        }
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            la[t][0][e] = lw[e * 48 + 16 * t];
+            la[t][1][e] = lw[(4 + e) * 48 + 16 * t];
+          }
       }
       const unsigned* rsl = rb + sl * (S * 32);
 #pragma unroll 1
       for (int c5 = 0; c5 < CPS; ++c5) {
         const int nxt = (chunk + 1 == NCH) ? 0 : chunk + 1;
         if (!(ABL & 2)) OVN_DMA_W((ABL & 64) ? 0 : nxt, cur ^ 1)
-        if (!(ABL & 8) && c5 == 1) OVN_DMA_L((sl + 1) & 3)                       // this wave read its la registers a barrier ago
+        if (!(ABL & 8) && c5 == 1) OVN_DMA_L((sl + 1 == ns) ? 0 : sl + 1)        // this wave read its la registers a barrier ago
         if (!(ABL & 16) && c5 == 2 && q4 == 0 && pass + 1 < p_end) OVN_DMA_R(pass + 1, rcur ^ 1)
         // operand fragments of step h+1 are read from LDS while step h's MFMAs run (two register sets, static indices)
         u32x4 rw[2][4];
@@ -1060,7 +1163,8 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   return al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + 2 * al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
          al((size_t)n * LIN_ELEMS * sizeof(float)) + al((size_t)(per_pair_right ? n : 1) * A2_KSPLIT * A2_ELEMS * sizeof(float)) +
-         al((size_t)n * O1RAW_ELEMS * sizeof(float)) + al((size_t)n * sizeof(DeltaDesc)) + al(QBLOCK_WORDS * sizeof(unsigned));
+         al((size_t)n * O1RAW_ELEMS * sizeof(float)) + al((size_t)n * sizeof(DeltaDesc)) + al(QBLOCK_WORDS * sizeof(unsigned)) +
+         al(LIVE_WORDS * sizeof(unsigned)) + al((size_t)S * FC * O1 * 2 * sizeof(_Float16));
 }
 
 static int pick_nsplit(int n) {
@@ -1105,16 +1209,27 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   DeltaDesc* desc = reinterpret_cast<DeltaDesc*>(p);
   p += al((size_t)n * sizeof(DeltaDesc));
   unsigned* qblock = reinterpret_cast<unsigned*>(p);
+  p += al(QBLOCK_WORDS * sizeof(unsigned));
+  unsigned* live_buf = reinterpret_cast<unsigned*>(p);
+  p += al(LIVE_WORDS * sizeof(unsigned));
+  _Float16* w1c = reinterpret_cast<_Float16*>(p);
+  // 1-vs-N sweeps (one query for all pairs): the query's live-channel list and the W1 fragments gathered for it; indexed pairs walk
+  // the plain K (every pair has its own right volume)
+  const unsigned* live = ridx ? nullptr : live_buf;
   *o2max_out = o2max;
   const int nsplit = pick_nsplit(n);   // 24: half-passes (one column group per workgroup), chosen for <= 10 pairs
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
-    if (dcache_l) hipLaunchKernelGGL(delta_query_kernel, dim3(QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock);
+    if (live) {
+      hipLaunchKernelGGL(delta_live_kernel, dim3(1), dim3(512), 0, stream, feats_r, live_buf);
+      hipLaunchKernelGGL(delta_w1c_kernel, dim3(240), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(ctx->w1p_h), live, w1c);
+    }
+    if (dcache_l) hipLaunchKernelGGL(delta_query_kernel, dim3(QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock, live);
     hipLaunchKernelGGL(delta_prepare_split_kernel<false>, dim3(n), dim3(512), PREP_SPLIT_LDS, stream, feats_l, lidx, feats_r, ridx,
                        reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1, a2raw,
                        reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->w2sum, ctx->c2.bias, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.sws,
-                       ctx->hs.w1_colsum, ctx->hs.b1_absmax, 1.0f, scales, o2max, pl, pr, lin, desc, dcache_l, qblock, (float*)nullptr);
+                       ctx->hs.w1_colsum, ctx->hs.b1_absmax, 1.0f, scales, o2max, pl, pr, lin, desc, dcache_l, qblock, (float*)nullptr, live);
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA, stream);
@@ -1124,14 +1239,14 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), lds);              \
     if (rc) return rc;                                                                                                       \
     hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, desc,         \
-                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx);                \
+                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);     \
   }
     if (nsplit == 24) {
       constexpr size_t lds = 2 * (size_t)3 * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;
       rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<3, 0, 1>), lds);
       if (rc) return rc;
       hipLaunchKernelGGL((delta_c1_f16x3_kernel<3, 0, 1>), dim3(n * nsplit), dim3(512), lds, stream, desc,
-                         reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx);
+                         reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
     } else
 #ifdef OVN_ABLATE
     switch (getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0) {   // tools/experiments/c1_variants.py
@@ -1177,7 +1292,7 @@ int ovn_delta_cache_forward(ovn_ctx* ctx, const float* feats, int n, float* cach
                      (const float*)nullptr, reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->w2sum, ctx->c2.bias, ctx->hs.sw1,
                      ctx->hs.sw2, ctx->hs.sws, ctx->hs.w1_colsum, ctx->hs.b1_absmax, 1.0f, (f32x4*)nullptr, (unsigned*)nullptr,
                      (unsigned*)nullptr, (unsigned*)nullptr, (float*)nullptr, (DeltaDesc*)nullptr, (const float*)nullptr,
-                     (const unsigned*)nullptr, cache);
+                     (const unsigned*)nullptr, cache, (const unsigned*)nullptr);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }
