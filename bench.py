@@ -68,8 +68,9 @@ HEAD_KERNEL = {
     "f16x3": ("delta_c1_f16x3_kernel (DeltaLayer in min form + c_conv1, fp16 MFMA)", PEAK_16BIT_MFMA_TFLOPS, "delta_c1_f16x3",
               DELTA_C1_FLOP_PER_PAIR,
               "achieved counts ALGORITHMIC flops of DeltaLayer + c_conv1 (93.8 % of the Delta head's flops; c_conv2 and the linear "
-              "terms run in delta_c2 / delta_prep, see kernels); the 3-term split issues 3 MFMA flops per algorithmic flop, so "
-              "the matrix pipe executes 3x this rate (frac <= 1/3 by construction)"),
+              "terms run in delta_c2 / delta_prep, see kernels); the 3-term split issues 3 MFMA flops per algorithmic flop WALKED, and "
+              "a 1-vs-N sweep walks only the channels that are alive in the query (k_walk_frac of the 128, exact: query_live_channels; "
+              "dense_walk_pairs_per_s = the same step with ovn_set_head_compaction 0)"),
 }
 DTYPE_LABEL = {
     "f32": "f32",
@@ -333,6 +334,8 @@ def main():
                     help="correlation head: spectral form on cached candidate spectra (default) or direct Gram form")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the gather even with one rank (path check)")
     ap.add_argument("--no-delta-cache", action="store_true", help="warm sweep without the candidates' Delta cache rows (round-2 behaviour)")
+    ap.add_argument("--no-compaction", action="store_true",
+                    help="walk all 128 feature channels in the Delta contraction even where the query's are dead (ovn_set_head_compaction 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-query", action="store_true", help="warm mode: the query leg on the heads' stream, in front of them (no QueryAhead)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32_mode / cold / fullstack / corr_head sub-records")
@@ -412,6 +415,7 @@ def main():
     w = S.make_test_weights(C, seed=0)
     eng.load_weights(w, S.REFERENCE_MODEL_CFG)
     eng.set_head_precision(args.head_precision)
+    eng.set_head_compaction(not args.no_compaction)
     if args.leg_precision:
         eng.set_leg_precision(args.leg_precision)
     leg_precision = eng.leg_precision
@@ -575,6 +579,17 @@ def main():
         launch_pairs = P * args.steps / d_n
     kname, peak, kprefix, flop_per_pair, rl_note = HEAD_KERNEL[args.head_precision]
     achieved = flop_per_pair * launch_pairs / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
+    # dead-channel compaction (ovn_set_head_compaction): the contraction walks ceil(live / 32) of the 4 channel slices, where `live`
+    # counts the channels that are non-zero somewhere in the QUERY's 360 columns -- measured here on the queries of the timed stream
+    live_counts, slices = [], []
+    if args.mode == "warm" and args.head_precision == "f16x3":
+        for qi in query_ring:
+            fq = eng.leg(qi)[0]
+            nl = int((fq != 0).any(dim=0).sum().item())
+            live_counts.append(nl)
+            slices.append(4 if (args.no_compaction or float(fq.min().item()) < 0) else max(1, -(-nl // 32)))
+    walk_frac = (sum(slices) / (4.0 * len(slices))) if slices else 1.0
+    mfma_per_alg = (3.0 * walk_frac) if args.head_precision == "f16x3" else 1.0
     if strong:
         workload = ("1-vs-%d synthetic candidate pool sharded over %d rank(s) in contiguous blocks (BASELINE configs[3]; warm: 1 query "
                     "leg per rank + %d head pairs per step in total), feature volumes generated on the device, 64x900x%d query"
@@ -602,8 +617,10 @@ def main():
                      "frac": achieved / peak, "traffic": None,
                      "flop_per_launch": flop_per_pair * launch_pairs, "pairs_per_launch": launch_pairs,
                      "avg_launch_ms": avg_ms,
-                     "mfma_flops_per_algorithmic_flop": 3 if args.head_precision == "f16x3" else 1,
-                     "frac_executed": (3 if args.head_precision == "f16x3" else 1) * achieved / peak,
+                     "mfma_flops_per_algorithmic_flop": mfma_per_alg,
+                     "frac_executed": mfma_per_alg * achieved / peak,
+                     "query_live_channels": (sum(live_counts) / len(live_counts)) if live_counts else None,
+                     "k_walk_frac": walk_frac,
                      "delta_total_ms": sum(prof[k][0] / max(prof[k][1], 1) for k in ("delta_prep", "delta_c12", "delta_c2") if k in prof),
                      "note": rl_note + ("; the next query's leg kernels run on a second stream beside this kernel (QueryAhead): its event "
                                         "time includes the CUs they take at its round boundaries" if qa is not None else "")},
@@ -693,6 +710,16 @@ def main():
             out["warm_serial"] = {"value": P * sub_steps / e0, "unit": "pairs/s", "ms_per_step": 1e3 * e0 / sub_steps, "steps": sub_steps,
                                   "step": "1 query leg, then %d head pairs, one stream" % P,
                                   "same_results": streamed_same}     # query 0 through both orders, after the timed region
+        # (0b) the same streamed step walking all 128 channels (no dead-channel compaction): what a query without dead channels costs
+        if not args.no_compaction:
+            eng.set_head_compaction(False)
+            try:
+                e0b, p0b, r0b = timed(step_warm, 2, sub_steps, eng, False, dev, side_eng=qa.side if qa is not None else None)
+            finally:
+                eng.set_head_compaction(True)
+            out["dense_walk"] = {"value": P * sub_steps / e0b, "unit": "pairs/s", "ms_per_step": 1e3 * e0b / sub_steps, "steps": sub_steps,
+                                 "delta_c12_ms": p0b["delta_c12"][0] / max(p0b["delta_c12"][1], 1),
+                                 "step": "the timed step with ovn_set_head_compaction(0): every pair walks all 128 feature channels"}
         # (1) everything on the fp32 matrix cores, direct correlation form
         eng.set_head_precision("f32")
         eng.set_leg_precision("f32")
@@ -830,23 +857,22 @@ def main():
     #      default single-GPU warm configuration, else the newest committed profile; never silently ----
     traffic_mode = args.traffic if (world == 1 and not strong and args.mode == "warm" and not args.no_extras) else \
         ("none" if args.traffic == "none" else "committed")
-    pass_args = ["--pool", str(P), "--channels", str(C), "--head-precision", args.head_precision, "--corr", args.corr]
+    pass_args = ["--pool", str(P), "--channels", str(C), "--head-precision", args.head_precision, "--corr", args.corr] + \
+        (["--no-compaction"] if args.no_compaction else [])
     t_bytes, t_src = rocprof_traffic(kprefix, traffic_mode, pass_args)
     # the scalars DESIGN.md quotes, copied into `roofline`: the driver's record keeps the first ~24 keys of that object (names cut at 40
     # characters, strings at 120), sub-records survive only as key names -- so the object is built in ORDER OF IMPORTANCE; all measured
     # in THIS run
     rl0 = out["roofline"]
     rl0["traffic"] = t_bytes
-    rl = {k: rl0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frac_executed")}
-    if args.head_precision == "f16x3":
-        # executed MFMA rate against what a bare MFMA loop sustains on real operands (a committed measurement, not this run's)
-        rl["executed_frac_of_sustained_mfma_rate"] = 3 * rl0["achieved"] / SUSTAINED_16BIT_MFMA_TFLOPS
-    rl["traffic_from"] = (t_src.get("source") or "none") if isinstance(t_src, dict) else str(t_src)
-    rl["step_pairs_per_s"] = out["value"]
+    rl = {k: rl0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "k_walk_frac")}
 
     def sub(name, key, as_name):
         if name in out and key in out[name]:
             rl[as_name] = out[name][key]
+    sub("dense_walk", "value", "dense_walk_pairs_per_s")
+    rl["step_pairs_per_s"] = out["value"]
+
     sub("cold", "value", "cold_pairs_per_s")
     sub("cold", "leg_scans_per_s", "cold_leg_scans_per_s")
     sub("cold", "leg_frac_of_16bit_mfma_peak_algorithmic", "cold_leg_frac_of_mfma_peak")
@@ -867,8 +893,13 @@ def main():
             rl["latency_n1_ms"] = rec["ms_per_query"]
         if "ms_per_query_streamed" in rec:
             rl["latency_n1_streamed_ms"] = rec["ms_per_query_streamed"]
-    sub("fp32_mode", "value", "fp32_mode_pairs_per_s")
+    rl["traffic_from"] = (t_src.get("source") or "none") if isinstance(t_src, dict) else str(t_src)
     # ---- (beyond the driver's 24 keys: kept in the line itself) ----
+    if args.head_precision == "f16x3":
+        # executed MFMA rate against what a bare MFMA loop sustains on real operands (a committed measurement, not this run's)
+        rl["executed_frac_of_sustained_mfma_rate"] = mfma_per_alg * rl0["achieved"] / SUSTAINED_16BIT_MFMA_TFLOPS
+    rl["avg_launch_ms"] = rl0["avg_launch_ms"]
+    sub("fp32_mode", "value", "fp32_mode_pairs_per_s")
     sub("warm_serial", "value", "warm_serial_pairs_per_s")
     if "yaw_exact_rate" in out:
         rl["yaw_exact_rate"] = out["yaw_exact_rate"]

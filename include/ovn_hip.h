@@ -39,7 +39,7 @@ typedef struct ovn_ctx ovn_ctx;
 #define OVN_ERR_STATE 3    /* call order (weights missing ...)  */
 
 /* ABI version of this header; bumped on any signature change. */
-#define OVN_ABI_VERSION 4
+#define OVN_ABI_VERSION 5
 int ovn_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -228,6 +228,13 @@ int ovn_set_head_precision(ovn_ctx* ctx, int mode);
 
 /* Arithmetic of the leg convolutions, same two modes as ovn_set_head_precision (default 1). */
 int ovn_set_leg_precision(ovn_ctx* ctx, int mode);
+
+/* Dead-channel compaction of the Delta head's contraction in 1-vs-N sweeps (default 1).  DeltaLayer + c_conv1
+ * (generateNet.py:45-59,96-100) sum |l - r| w over the 128 feature channels; in the min form of the f16x3 path a channel that is 0
+ * in all 360 columns of the QUERY (ReLU outputs: a quarter of the channels under the benchmark's weights) contributes exact zeros
+ * for every candidate, so the K walk covers only ceil(live / 32) slices of 32 channels.  Exact; changes only how K is grouped into
+ * MFMA steps (last-bit differences against on = 0).  Pairs with negative values and indexed pairs always walk all 128 channels. */
+int ovn_set_head_compaction(ovn_ctx* ctx, int on);
 
 /* Which float32 `np.arctan2` / `np.arcsin` (src/utils/utils.py:86-87) ovn_project / ovn_projection_angles reproduce:
  *   0 (default)  NumPy >= 1.22 on an AVX512_SKX x86-64 host: Intel SVML's 1-4 ulp kernels, bit for bit (csrc/svml_f32.h) -- the

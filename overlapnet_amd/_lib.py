@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libovn_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -50,6 +50,7 @@ SIGNATURES = {
     "ovn_set_head_precision": (C.c_int, [_vp, C.c_int]),
     "ovn_set_leg_precision": (C.c_int, [_vp, C.c_int]),
     "ovn_set_projection_trig": (C.c_int, [_vp, C.c_int]),
+    "ovn_set_head_compaction": (C.c_int, [_vp, C.c_int]),
     "ovn_profile_begin": (C.c_int, [_vp]),
     "ovn_profile_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ovn_debug_conv": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),

@@ -306,58 +306,81 @@ __device__ __forceinline__ int load_chan_table(const unsigned* __restrict__ live
   return use ? (int)live[0] : 4;
 }
 
-// One workgroup per query: which channels are alive, in walk order; identity when the volume has a negative value.
+// Channel list of a query from its per-channel flags (alive[ch] != 0: some column of the query is non-zero there; `shifted`: the
+// volume has a negative value -> every channel counts as alive): live channels first, then the dead ones, both in walk order.
+// Threads 0 .. 127 of the workgroup take one walk position each; every thread must call it.  `scr`: 4 words of LDS scratch.
+// Returns the number of live channels (valid after the call's trailing barrier).
+__device__ __forceinline__ int build_chan_list(const int* alive, bool shifted, unsigned char* chan_s, unsigned long long* scr, int tid) {
+  const int ch = ident_chan(tid & (FC - 1));
+  const bool a = tid < FC && (shifted || alive[ch] != 0);
+  const unsigned long long m = __ballot(a);
+  if (tid < FC && (tid & 63) == 0) scr[tid >> 6] = m;
+  __syncthreads();
+  const unsigned long long m0 = scr[0], m1 = scr[1];
+  const int nlive = __popcll(m0) + __popcll(m1);
+  if (tid < FC) {
+    const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+    const int live_before = (tid < 64) ? __popcll(m0 & below) : __popcll(m0) + __popcll(m1 & below);
+    chan_s[a ? live_before : nlive + (tid - live_before)] = (unsigned char)ch;
+  }
+  __syncthreads();
+  return nlive;
+}
+
+// One workgroup per query: which channels are alive, in walk order (1-vs-N sweeps WITHOUT Delta cache rows: with them the query
+// kernel below builds the list itself).
 __global__ __launch_bounds__(512) void delta_live_kernel(const float* __restrict__ feats_r, unsigned* __restrict__ live) {
-  __shared__ int alive[4][FC];
+  __shared__ int alive[FC];
   __shared__ int neg_s;
-  __shared__ unsigned char chan_s[FC];
+  __shared__ unsigned long long scr[2];
+  __shared__ __attribute__((aligned(16))) unsigned char chan_s[FC];
   const int tid = threadIdx.x, c = tid & (FC - 1), part = tid >> 7;
+  if (tid < FC) alive[tid] = 0;
   if (tid == 0) neg_s = 0;
+  __syncthreads();
   int any = 0, ng = 0;
   for (int j = part; j < FW; j += 4) {
     const float v = feats_r[(size_t)j * FC + c];
     any |= (v != 0.0f);
     ng |= (v < 0.0f);
   }
-  alive[part][c] = any;
+  if (any) alive[c] = 1;
+  if (ng) neg_s = 1;
   __syncthreads();
-  if (ng) atomicOr(&neg_s, 1);
-  __syncthreads();
+  const int nlive = build_chan_list(alive, neg_s != 0, chan_s, scr, tid);
   if (tid == 0) {
-    int n = 0;
-    const bool shifted = neg_s != 0;
-    for (int pos = 0; pos < FC; ++pos) {          // live channels first, in walk order
-      const int ch = ident_chan(pos);
-      if (shifted || (alive[0][ch] | alive[1][ch] | alive[2][ch] | alive[3][ch])) chan_s[n++] = (unsigned char)ch;
-    }
-    const int nlive = n;
-    for (int pos = 0; pos < FC && n < FC; ++pos) {  // dead ones behind them (they pad the last slice, exact zeros)
-      const int ch = ident_chan(pos);
-      if (!(shifted || (alive[0][ch] | alive[1][ch] | alive[2][ch] | alive[3][ch]))) chan_s[n++] = (unsigned char)ch;
-    }
-    int ns = (nlive + 31) / 32;
+    const int ns = (nlive + 31) / 32;
     live[0] = (unsigned)(ns < 1 ? 1 : ns);
     live[1] = (unsigned)nlive;
     live[2] = live[3] = 0u;
   }
-  __syncthreads();
   if (tid < FC / 4) live[4 + tid] = reinterpret_cast<const unsigned*>(chan_s)[tid];
 }
 
-// W1 fragments of the compacted walk: out[sc][dj][nt][hi,lo][lane][e] = w1p[...] of channel chan[32 sc + 8 (lane >> 4) + e]
+// 8 consecutive elements (one lane's 16 bytes) of the compacted W1 fragments: out[sc][dj][nt][hi,lo][lane][0..7] <- w1p[...] of the
+// channels chan[32 sc + 8 (lane >> 4) + e]
+__device__ __forceinline__ void w1c_gather8(const _Float16* __restrict__ w1p, const unsigned char* chan, int idx8, _Float16* __restrict__ w1c) {
+  const int lane = idx8 & 63, hl = (idx8 >> 6) & 1, nt = (idx8 >> 7) & 3;
+  const int step = idx8 >> 9;                   // sc * 15 + dj
+  const int sc = step / S, dj = step - sc * S;
+  const unsigned char* cp = chan + 32 * sc + 8 * (lane >> 4);
+  f16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int ch = cp[e];
+    const int src_step = ((ch & 31) >> 3) * S + dj;
+    v[e] = w1p[((((size_t)src_step * 4 + nt) * 2 + hl) * 64 + (lane & 15) + 16 * (ch >> 5)) * 8 + (ch & 7)];
+  }
+  *reinterpret_cast<f16x8*>(w1c + (size_t)idx8 * 8) = v;
+}
+
+// W1 fragments of the compacted walk (the no-cache route; see delta_live_kernel)
 __global__ __launch_bounds__(256) void delta_w1c_kernel(const _Float16* __restrict__ w1p, const unsigned* __restrict__ live,
                                                         _Float16* __restrict__ w1c) {
   const int ns = (int)live[0];
   const unsigned char* chan = reinterpret_cast<const unsigned char*>(live + 4);
-  const int total = ns * S * 4 * 2 * 512;
-  for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
-    const int e = idx & 7, lane = (idx >> 3) & 63, hl = (idx >> 9) & 1, nt = (idx >> 10) & 3;
-    const int step = idx >> 12;                   // sc * 15 + dj
-    const int sc = step / S, dj = step - sc * S;
-    const int ch = chan[32 * sc + 8 * (lane >> 4) + e];
-    const int src_step = ((ch & 31) >> 3) * S + dj;
-    w1c[idx] = w1p[((((size_t)src_step * 4 + nt) * 2 + hl) * 64 + (lane & 15) + 16 * (ch >> 5)) * 8 + (ch & 7)];
-  }
+  const int total8 = ns * S * 4 * 2 * 64;
+  for (int idx8 = blockIdx.x * 256 + threadIdx.x; idx8 < total8; idx8 += gridDim.x * 256) w1c_gather8(w1p, chan, idx8, w1c);
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
@@ -715,9 +738,12 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
 // Same arithmetic, in the same order, as the R / AA parts of delta_prepare_split_kernel with shift c = 0.
 __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restrict__ feats_r, const float* __restrict__ a2raw,
                                                           const float* __restrict__ w2sum, unsigned* __restrict__ qblock,
-                                                          const unsigned* __restrict__ live) {
+                                                          unsigned* __restrict__ live_out, const _Float16* __restrict__ w1p,
+                                                          _Float16* __restrict__ w1c) {
   __shared__ float red[2 * NWAVE];
   __shared__ float A2l[G * O1];
+  __shared__ int alive[FC];
+  __shared__ unsigned long long scr[2];
   __shared__ __attribute__((aligned(16))) unsigned char chan_q[FC];
   const int ver = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -725,6 +751,7 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
   constexpr int R_ITEMS = OVN_FEAT_ELEMS / 8;
   f32x4 rv[12][2];
   float mx = -3.0e38f, mn = 3.0e38f;
+  if (tid < FC) alive[tid] = 0;
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const int i8 = tid + 512 * k;
@@ -735,13 +762,23 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
       rv[k][0] = rv[k][1] = R4[0];
     }
   }
+  // item i8 = (row i8 / 16, channels 8 (i8 % 16) ..): a thread sees the same eight channels in all its items (512 % 16 == 0)
+  f32x4 nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 12; ++k)
+  for (int k = 0; k < 12; ++k) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       mx = fmaxf(mx, fmaxf(fmaxf(rv[k][h][0], rv[k][h][1]), fmaxf(rv[k][h][2], rv[k][h][3])));
       mn = fminf(mn, fminf(fminf(rv[k][h][0], rv[k][h][1]), fminf(rv[k][h][2], rv[k][h][3])));
     }
+    if (tid + 512 * k < R_ITEMS) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        nz0[e] = (rv[k][0][e] != 0.0f) ? 1.0f : nz0[e];
+        nz1[e] = (rv[k][1][e] != 0.0f) ? 1.0f : nz1[e];
+      }
+    }
+  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     mx = fmaxf(mx, __shfl_down(mx, off, 64));
@@ -751,7 +788,12 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
     red[wave] = mx;
     red[NWAVE + wave] = mn;
   }
-  __syncthreads();
+  __syncthreads();   // (also: alive[] cleared)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (nz0[e] != 0.0f) alive[8 * (tid & 15) + e] = 1;
+    if (nz1[e] != 0.0f) alive[8 * (tid & 15) + 4 + e] = 1;
+  }
   mx = red[0];
   mn = red[NWAVE];
 #pragma unroll
@@ -759,12 +801,31 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
     mx = fmaxf(mx, red[w]);
     mn = fminf(mn, red[NWAVE + w]);
   }
+  __syncthreads();
   const float sa = ldexpf(ovn_pow2_scale_for(mx), -ver);
   unsigned* Pr = qblock + (size_t)ver * OVN_FEAT_ELEMS;
-  // the words in the order of the query's compacted K walk (`live`; a volume with a negative value has the identity list there, and
-  // no cached pair uses it anyway)
-  const int ns = load_chan_table(live, live != nullptr, chan_q, tid);
-  __syncthreads();
+  // The query's K walk: live channels only (every workgroup builds the same list; workgroup 0 leaves it in `live_out` for the
+  // prepare and contraction kernels), plain order when the sweep does not compact (live_out NULL) or the volume has a negative value
+  int ns = 4;
+  if (live_out != nullptr) {
+    const int nlive = build_chan_list(alive, mn < 0.0f, chan_q, scr, tid);
+    ns = (nlive + 31) / 32;
+    ns = ns < 1 ? 1 : ns;
+    if (ver == 0) {
+      if (tid == 0) {
+        live_out[0] = (unsigned)ns;
+        live_out[1] = (unsigned)nlive;
+        live_out[2] = live_out[3] = 0u;
+      }
+      if (tid < FC / 4) live_out[4 + tid] = reinterpret_cast<const unsigned*>(chan_q)[tid];
+    }
+    // this workgroup's share of the W1 fragments gathered for the list
+    const int total8 = ns * S * 4 * 2 * 64;
+    for (int idx8 = ver * 512 + tid; idx8 < total8; idx8 += QV * 512) w1c_gather8(w1p, chan_q, idx8, w1c);
+  } else {
+    (void)load_chan_table(nullptr, false, chan_q, tid);
+    __syncthreads();
+  }
 #pragma unroll 2
   for (int k = 0; k < 12; ++k) {
     const int i8 = tid + 512 * k;
@@ -1215,17 +1276,19 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   _Float16* w1c = reinterpret_cast<_Float16*>(p);
   // 1-vs-N sweeps (one query for all pairs): the query's live-channel list and the W1 fragments gathered for it; indexed pairs walk
   // the plain K (every pair has its own right volume)
-  const unsigned* live = ridx ? nullptr : live_buf;
+  const unsigned* live = (ridx || !ctx->head_compact) ? nullptr : live_buf;
   *o2max_out = o2max;
   const int nsplit = pick_nsplit(n);   // 24: half-passes (one column group per workgroup), chosen for <= 10 pairs
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
-    if (live) {
+    if (dcache_l) {   // the query kernel also builds the live-channel list and gathers the W1 fragments for it
+      hipLaunchKernelGGL(delta_query_kernel, dim3(QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock, live ? live_buf : nullptr,
+                         reinterpret_cast<const _Float16*>(ctx->w1p_h), w1c);
+    } else if (live) {
       hipLaunchKernelGGL(delta_live_kernel, dim3(1), dim3(512), 0, stream, feats_r, live_buf);
       hipLaunchKernelGGL(delta_w1c_kernel, dim3(240), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(ctx->w1p_h), live, w1c);
     }
-    if (dcache_l) hipLaunchKernelGGL(delta_query_kernel, dim3(QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock, live);
     hipLaunchKernelGGL(delta_prepare_split_kernel<false>, dim3(n), dim3(512), PREP_SPLIT_LDS, stream, feats_l, lidx, feats_r, ridx,
                        reinterpret_cast<const _Float16*>(ctx->wsp_h), ctx->w1col, ctx->b1, a2raw,
                        reinterpret_cast<const _Float16*>(ctx->w2p_h), ctx->w2sum, ctx->c2.bias, ctx->hs.sw1, ctx->hs.sw2, ctx->hs.sws,

@@ -711,6 +711,13 @@ int ovn_set_head_precision(ovn_ctx* ctx, int mode) {
   return OVN_OK;
 }
 
+int ovn_set_head_compaction(ovn_ctx* ctx, int on) {
+  OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_head_compaction: ctx is NULL");
+  OVN_REQUIRE(on == 0 || on == 1, OVN_ERR_ARG, "ovn_set_head_compaction: %d (0 = walk all 128 channels, 1 = drop the query's dead channels)", on);
+  ctx->head_compact = on;
+  return OVN_OK;
+}
+
 int ovn_set_projection_trig(ovn_ctx* ctx, int mode) {
   OVN_REQUIRE(ctx != nullptr, OVN_ERR_ARG, "ovn_set_projection_trig: ctx is NULL");
   OVN_REQUIRE(mode == 0 || mode == 1, OVN_ERR_ARG, "ovn_set_projection_trig: mode %d (0 = NumPy / SVML float32, 1 = correctly rounded)", mode);

@@ -161,6 +161,7 @@ struct ovn_ctx {
   float* w2sum = nullptr;  // c_conv2 kernel summed over its 15 taps, [64][128]: the right-volume linear term pushed through c_conv2
   OvnHeadScales hs;
   int leg_mode = 1;        // 0 = fp32 MFMA (conv_f32.hip), 1 = scaled 3-term fp16 split on the fp16 MFMA (conv_f16x3.hip)
+  int head_compact = 1;    // ovn_set_head_compaction: 1 = 1-vs-N sweeps drop the query's dead channels from the Delta contraction (exact)
   int proj_trig = 0;       // ovn_set_projection_trig: 0 = NumPy-on-AVX512 (SVML) float32 angles, 1 = correctly rounded float32 angles
   unsigned* actmax = nullptr;   // [layer][scan of the slice][OVN_ACTMAX_STRIDE] float bits of max |layer input| of that scan (f16x3 scales)
   int head_mode = 1;       // 0 = fp32 MFMA (exact fp32), 1 = scaled 3-term fp16 split on the fp16 MFMA (default)

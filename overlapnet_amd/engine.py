@@ -47,6 +47,7 @@ class OvnEngine:
         self.head_precision = "f16x3"
         self.leg_precision = "f16x3"
         self.projection_trig = "numpy_avx512"
+        self.head_compaction = True
         self.conv1size = 15
         self.check_device_indices = False    # opt-in range check of pair-index tensors that already live on the device (_idx)
 
@@ -434,6 +435,12 @@ class OvnEngine:
             raise ValueError("head precision must be one of %s" % sorted(table))
         _lib.check(self.lib.ovn_set_head_precision(self._h, table[mode]), "ovn_set_head_precision")
         self.head_precision = mode
+
+    def set_head_compaction(self, on: bool) -> None:
+        """1-vs-N sweeps drop the query's dead feature channels (zero in all 360 columns) from the Delta head's contraction (default on;
+        exact -- include/ovn_hip.h: ovn_set_head_compaction).  Off: every pair walks all 128 channels, as indexed pairs always do."""
+        _lib.check(self.lib.ovn_set_head_compaction(self._h, int(bool(on))), "ovn_set_head_compaction")
+        self.head_compaction = bool(on)
 
     def set_projection_trig(self, mode: str) -> None:
         """Which float32 `np.arctan2` / `np.arcsin` (utils.py:86-87) `project` reproduces: 'numpy_avx512' (default: NumPy >= 1.22 on an

@@ -1083,6 +1083,60 @@ def test_delta_cache_rows_follow_the_candidates_across_chunks(engines):
         e.set_head_pipeline(*saved)
 
 
+def test_dead_channel_compaction_of_the_query(engines):
+    """1-vs-N sweeps drop the channels that are zero in ALL 360 columns of the query from the Delta head's contraction
+    (`ovn_set_head_compaction`, default on): exact, so the results agree with the uncompacted walk (compaction off, and the indexed-pairs
+    form, which never compacts) to fp32 rounding and with the fp64 oracle within the north-star tolerance; a query WITHOUT a dead channel
+    walks the very K of the uncompacted kernel (same bits); a query with a negative value is never compacted (its shifted words have
+    no zeros); with and without the candidates' Delta cache rows the bits are the same in every case."""
+    e = engines[4]
+    w = S.make_test_weights(4, seed=0)
+    rng = np.random.default_rng(77)
+    n = 70
+    cands = np.maximum(rng.normal(0.2, 1.0, size=(n, 360, 128)), 0).astype(np.float32)
+    cands[:, :, [3, 40, 41, 100]] = 0                     # candidates have dead channels of their own (irrelevant to the list)
+    dc = torch.from_numpy(cands).cuda()
+    spec = e.spectrum(dc)
+    cache = e.delta_cache(dc)
+
+    def sweep(q, compaction, use_cache=True):
+        e.set_head_compaction(compaction)
+        try:
+            dq = torch.from_numpy(q).cuda()
+            r = e.heads(dc, dq, spec_l=spec, spec_r=e.spectrum(dq), dcache_l=cache if use_cache else None, want_logit=True)
+            return r["logit"].cpu().numpy(), r["overlap"].cpu().numpy(), r["yaw"].cpu().numpy()
+        finally:
+            e.set_head_compaction(True)
+
+    for dead in (0, 5, 33, 70, 127, 128):
+        q = np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)
+        kill = rng.permutation(128)[:dead]
+        q[:, :, kill] = 0
+        lg1, ov1, yw1 = sweep(q, True)
+        lg0, ov0, yw0 = sweep(q, False)
+        lgn, ovn, ywn = sweep(q, True, use_cache=False)
+        assert np.array_equal(lg1, lgn) and np.array_equal(yw1, ywn), dead          # cache rows or scratch: same bits
+        assert np.array_equal(yw1, yw0)
+        if dead == 0:
+            assert np.array_equal(lg1, lg0)                                           # nothing to drop: the uncompacted K walk
+        else:
+            assert np.max(np.abs(lg1 - lg0)) <= 2e-5 * (1 + np.max(np.abs(lg0))), dead
+        allf = torch.cat([dc, torch.from_numpy(q).cuda()])
+        ri = e.heads(allf, allf, lidx=np.arange(n), ridx=np.full(n, n, np.int64), want_logit=True)["logit"].cpu().numpy()
+        assert np.array_equal(ri, lg0)                                                # indexed pairs never compact
+        if dead in (33, 128):
+            fv = cands[:8].reshape(8, 1, 360, 128).astype(np.float64)
+            o_ov, o_yaw, o_lg, _ = O.heads_forward(fv, np.repeat(q.reshape(1, 1, 360, 128).astype(np.float64), 8, axis=0), w)
+            assert np.max(np.abs(ov1[:8] - o_ov)) <= 1e-4 and np.max(np.abs(lg1[:8] - o_lg)) <= 1e-3 * (1 + np.max(np.abs(o_lg)))
+    # a negative value anywhere in the query: the pair needs a shift, nothing is dropped -> the bits of the uncompacted walk
+    q = np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)
+    q[:, :, :40] = 0
+    q[0, 17, 5] = -0.25
+    lg1, _, yw1 = sweep(q, True)
+    lg0, _, yw0 = sweep(q, False)
+    assert np.array_equal(lg1, lg0) and np.array_equal(yw1, yw0)
+
+
 def test_delta_cache_is_ignored_where_it_does_not_apply(engines):
     """fp32 head mode and pair lists with their own right-hand volumes never use the Delta cache rows: same results as without."""
     e = engines[4]
