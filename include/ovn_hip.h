@@ -129,7 +129,7 @@ int ovn_corr_head_spectral(ovn_ctx* ctx, const float* spec_l_dev, const int32_t*
 
 /* Delta cache: everything of a pair's Delta-head preparation that depends on the LEFT volume (the candidate of a sweep) alone --
  * its feature volume re-written as the packed hi/lo fp16 words the contraction kernel streams (at the candidate's own power-of-two
- * scale), its linear term pushed through c_conv2 (TT + b2) and its value range.  OVN_DELTA_CACHE_ELEMS floats (196,864 B) per
+ * scale; channel-major [128][360], so that a sweep fetches only the channels alive in its query: ovn_set_head_compaction), its linear term pushed through c_conv2 (TT + b2) and its value range.  OVN_DELTA_CACHE_ELEMS floats (196,864 B) per
  * volume, cached next to the feature volume and the spectrum (the reference caches per-candidate state too: infer.py:184-185).
  * A row is used by ovn_heads_spectral for a pair whenever neither volume has a negative value and the query's largest value is
  * below the candidate's next power of two; every other pair is prepared in scratch as without a cache -- same bits either way.
