@@ -283,6 +283,7 @@ constexpr int DC_TT = OVN_FEAT_ELEMS;                // [24 * 128] floats
 constexpr int DC_META = DC_TT + G * O2;              // {max L, min L, 0, 0}
 static_assert(DC_META + 4 <= OVN_DELTA_CACHE_ELEMS, "Delta cache row too small");
 constexpr int QV = 8;                                // packed versions of the query: scales sa_q, sa_q / 2, ... sa_q / 128
+constexpr int QGW = 24;                              // further workgroups of delta_query_kernel that only help gather the W1 fragments
 // per-query operands shared by every cached pair of a sweep: [QV][46080] packed words | AA [24][128] | {max R, min R, 0, 0}
 constexpr size_t QBLOCK_WORDS = (size_t)QV * OVN_FEAT_ELEMS + G * O2 + 4;
 
@@ -802,8 +803,8 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
     mn = fminf(mn, red[NWAVE + w]);
   }
   __syncthreads();
-  const float sa = ldexpf(ovn_pow2_scale_for(mx), -ver);
-  unsigned* Pr = qblock + (size_t)ver * OVN_FEAT_ELEMS;
+  const float sa = ldexpf(ovn_pow2_scale_for(mx), -(ver < QV ? ver : 0));
+  unsigned* Pr = qblock + (size_t)(ver < QV ? ver : 0) * OVN_FEAT_ELEMS;
   // The query's K walk: live channels only (every workgroup builds the same list; workgroup 0 leaves it in `live_out` for the
   // prepare and contraction kernels), plain order when the sweep does not compact (live_out NULL) or the volume has a negative value
   int ns = 4;
@@ -819,9 +820,10 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
       }
       if (tid < FC / 4) live_out[4 + tid] = reinterpret_cast<const unsigned*>(chan_q)[tid];
     }
-    // this workgroup's share of the W1 fragments gathered for the list
+    // this workgroup's share of the W1 fragments gathered for the list (workgroups QV .. QV + QGW - 1 do nothing else)
     const int total8 = ns * S * 4 * 2 * 64;
-    for (int idx8 = ver * 512 + tid; idx8 < total8; idx8 += QV * 512) w1c_gather8(w1p, chan_q, idx8, w1c);
+    for (int idx8 = ver * 512 + tid; idx8 < total8; idx8 += gridDim.x * 512) w1c_gather8(w1p, chan_q, idx8, w1c);
+    if (ver >= QV) return;
   } else {
     (void)load_chan_table(nullptr, false, chan_q, tid);
     __syncthreads();
@@ -1283,7 +1285,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
     if (dcache_l) {   // the query kernel also builds the live-channel list and gathers the W1 fragments for it
-      hipLaunchKernelGGL(delta_query_kernel, dim3(QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock, live ? live_buf : nullptr,
+      hipLaunchKernelGGL(delta_query_kernel, dim3(live ? QV + QGW : QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock, live ? live_buf : nullptr,
                          reinterpret_cast<const _Float16*>(ctx->w1p_h), w1c);
     } else if (live) {
       hipLaunchKernelGGL(delta_live_kernel, dim3(1), dim3(512), 0, stream, feats_r, live_buf);
