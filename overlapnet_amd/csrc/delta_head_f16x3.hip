@@ -296,7 +296,10 @@ constexpr size_t QBLOCK_WORDS = (size_t)QV * OVN_FEAT_ELEMS + G * O2 + 4;
 // Exact (the dropped products are exact zeros); only the grouping of K into MFMA steps changes.  The list keeps the live channels in
 // the order of the uncompacted walk (slice s, lane group g, element e <-> channel 32 g + 8 s + e), so a query without dead channels
 // -- and any pair that needs a shift (negative values: r' = r + c has no zeros) -- walks exactly the K of rounds 2-4.
-constexpr int LIVE_WORDS = 4 + FC / 4;     // {ns, live channels, 0, 0} + 128 channel bytes: position 32 s + 8 g + e of the compacted walk
+constexpr int NPAIR = G / 2;               // column-group pairs (the passes of the contraction kernel)
+constexpr int LIVE_WORDS = 4 + FC / 4 + 4; // {largest slice count, live channels, 0, 0} | 128 channel bytes: position 32 s + 8 g + e of the
+                                           // compacted walk | slices to walk for column groups 2 p, 2 p + 1 (12 bytes, + 4 of padding)
+constexpr int CHAN_BYTES = FC + 16;        // the table in LDS: channel bytes + per-pair slice counts
 __device__ __forceinline__ int ident_chan(int pos) { return 32 * ((pos >> 3) & 3) + 8 * (pos >> 5) + (pos & 7); }
 __device__ __forceinline__ unsigned ident_chan_word(int w) {
   return (unsigned)ident_chan(4 * w) | (unsigned)ident_chan(4 * w + 1) << 8 | (unsigned)ident_chan(4 * w + 2) << 16 | (unsigned)ident_chan(4 * w + 3) << 24;
@@ -304,26 +307,48 @@ __device__ __forceinline__ unsigned ident_chan_word(int w) {
 // channel table of a workgroup -> LDS (`use`: workgroup-uniform); returns the number of slices.  Caller synchronises.
 __device__ __forceinline__ int load_chan_table(const unsigned* __restrict__ live, bool use, unsigned char* chan_s, int tid) {
   if (tid < FC / 4) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : ident_chan_word(tid);
+  else if (tid < FC / 4 + 4) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : 0x04040404u;
   return use ? (int)live[0] : 4;
 }
 
-// Channel list of a query from its per-channel flags (alive[ch] != 0: some column of the query is non-zero there; `shifted`: the
-// volume has a negative value -> every channel counts as alive): live channels first, then the dead ones, both in walk order.
-// Threads 0 .. 127 of the workgroup take one walk position each; every thread must call it.  `scr`: 4 words of LDS scratch.
-// Returns the number of live channels (valid after the call's trailing barrier).
-__device__ __forceinline__ int build_chan_list(const int* alive, bool shifted, unsigned char* chan_s, unsigned long long* scr, int tid) {
+// Channel list of a query from its flags alive2[p][ch] (channel ch is non-zero somewhere in the 30 query columns of column groups 2 p,
+// 2 p + 1; `shifted`: the volume has a negative value -> everything counts as alive).  The channels are ordered by the NUMBER OF
+// PAIRS p they are alive in (descending; ties and the dead ones in walk order -- a query alive everywhere gets the identity), and pair p
+// walks only up to the last position that is alive in it: nsp[p] = ceil(that / 32) slices.  One list, one set of gathered weights, and
+// a column-group pair whose own live channels fit fewer slices than the query's walks fewer (the benchmark's query: 94 live channels,
+// 3 slices everywhere; under the trained-like weights 99 live -> 4 slices as a whole, but 3 in ten of its twelve pairs).
+// Threads 0 .. 127 take one walk position each; every thread of the workgroup must call it.  `scr`: FC + 16 ints of LDS.
+// Leaves chan_s[0 .. 127] and chan_s[FC + p]; returns the number of live channels.
+__device__ __forceinline__ int build_chan_list(const int (*alive2)[FC], bool shifted, unsigned char* chan_s, int* scr, int tid) {
+  int* cnt_s = scr;            // [FC] pairs position q is alive in
+  int* nmax = scr + FC;        // [NPAIR] walk length of pair p; [NPAIR] live channels
   const int ch = ident_chan(tid & (FC - 1));
-  const bool a = tid < FC && (shifted || alive[ch] != 0);
-  const unsigned long long m = __ballot(a);
-  if (tid < FC && (tid & 63) == 0) scr[tid >> 6] = m;
-  __syncthreads();
-  const unsigned long long m0 = scr[0], m1 = scr[1];
-  const int nlive = __popcll(m0) + __popcll(m1);
+  int cnt = 0;
   if (tid < FC) {
-    const unsigned long long below = (1ull << (tid & 63)) - 1ull;
-    const int live_before = (tid < 64) ? __popcll(m0 & below) : __popcll(m0) + __popcll(m1 & below);
-    chan_s[a ? live_before : nlive + (tid - live_before)] = (unsigned char)ch;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) cnt += (shifted || alive2[p][ch] != 0) ? 1 : 0;
+    cnt_s[tid] = cnt;
   }
+  if (tid <= NPAIR) nmax[tid] = 0;
+  __syncthreads();
+  if (tid < FC) {
+    int rank = 0;
+    for (int q = 0; q < FC; ++q) {
+      const int cq = cnt_s[q];
+      rank += (cq > cnt || (cq == cnt && q < tid)) ? 1 : 0;
+    }
+    chan_s[rank] = (unsigned char)ch;
+    if (cnt > 0) atomicAdd(&nmax[NPAIR], 1);
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p)
+      if (shifted || alive2[p][ch] != 0) atomicMax(&nmax[p], rank + 1);
+  }
+  __syncthreads();
+  if (tid < 16) {
+    int ns = tid < NPAIR ? (nmax[tid] + 31) / 32 : 0;
+    chan_s[FC + tid] = (unsigned char)(tid < NPAIR ? (ns < 1 ? 1 : ns) : 4);
+  }
+  const int nlive = nmax[NPAIR];
   __syncthreads();
   return nlive;
 }
@@ -331,31 +356,31 @@ __device__ __forceinline__ int build_chan_list(const int* alive, bool shifted, u
 // One workgroup per query: which channels are alive, in walk order (1-vs-N sweeps WITHOUT Delta cache rows: with them the query
 // kernel below builds the list itself).
 __global__ __launch_bounds__(512) void delta_live_kernel(const float* __restrict__ feats_r, unsigned* __restrict__ live) {
-  __shared__ int alive[FC];
+  __shared__ int alive2[NPAIR][FC];
   __shared__ int neg_s;
-  __shared__ unsigned long long scr[2];
-  __shared__ __attribute__((aligned(16))) unsigned char chan_s[FC];
+  __shared__ int scr[FC + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char chan_s[CHAN_BYTES];
   const int tid = threadIdx.x, c = tid & (FC - 1), part = tid >> 7;
-  if (tid < FC) alive[tid] = 0;
+  for (int i = tid; i < NPAIR * FC; i += 512) (&alive2[0][0])[i] = 0;
   if (tid == 0) neg_s = 0;
   __syncthreads();
-  int any = 0, ng = 0;
+  int ng = 0;
   for (int j = part; j < FW; j += 4) {
     const float v = feats_r[(size_t)j * FC + c];
-    any |= (v != 0.0f);
+    if (v != 0.0f) alive2[j / (2 * S)][c] = 1;
     ng |= (v < 0.0f);
   }
-  if (any) alive[c] = 1;
   if (ng) neg_s = 1;
   __syncthreads();
-  const int nlive = build_chan_list(alive, neg_s != 0, chan_s, scr, tid);
+  const int nlive = build_chan_list(alive2, neg_s != 0, chan_s, scr, tid);
   if (tid == 0) {
-    const int ns = (nlive + 31) / 32;
-    live[0] = (unsigned)(ns < 1 ? 1 : ns);
+    int nsm = 1;
+    for (int p = 0; p < NPAIR; ++p) nsm = chan_s[FC + p] > nsm ? chan_s[FC + p] : nsm;
+    live[0] = (unsigned)nsm;
     live[1] = (unsigned)nlive;
     live[2] = live[3] = 0u;
   }
-  if (tid < FC / 4) live[4 + tid] = reinterpret_cast<const unsigned*>(chan_s)[tid];
+  if (tid < FC / 4 + 4) live[4 + tid] = reinterpret_cast<const unsigned*>(chan_s)[tid];
 }
 
 // 8 consecutive elements (one lane's 16 bytes) of the compacted W1 fragments: out[sc][dj][nt][hi,lo][lane][0..7] <- w1p[...] of the
@@ -415,7 +440,7 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     float* __restrict__ lin, DeltaDesc* __restrict__ desc, const float* __restrict__ dcache, const unsigned* __restrict__ qblock,
     float* __restrict__ cache_out, const unsigned* __restrict__ live) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
-  __shared__ __attribute__((aligned(16))) unsigned char chan_p[FC];
+  __shared__ __attribute__((aligned(16))) unsigned char chan_p[CHAN_BYTES];
   // T image, scaled fp16 hi / lo: T[15 ib + di][o] at [ib][di * 64 + 4 (o & 15) + (o >> 4)] (the K order of W2p)
   _Float16* Th = reinterpret_cast<_Float16*>(psm);
   _Float16* Tlo = Th + G * TT_STRIDE;
@@ -743,16 +768,16 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
                                                           _Float16* __restrict__ w1c) {
   __shared__ float red[2 * NWAVE];
   __shared__ float A2l[G * O1];
-  __shared__ int alive[FC];
-  __shared__ unsigned long long scr[2];
-  __shared__ __attribute__((aligned(16))) unsigned char chan_q[FC];
+  __shared__ int alive2[NPAIR][FC];
+  __shared__ int scr[FC + 16];
+  __shared__ __attribute__((aligned(16))) unsigned char chan_q[CHAN_BYTES];
   const int ver = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const f32x4* R4 = reinterpret_cast<const f32x4*>(feats_r);
   constexpr int R_ITEMS = OVN_FEAT_ELEMS / 8;
   f32x4 rv[12][2];
   float mx = -3.0e38f, mn = 3.0e38f;
-  if (tid < FC) alive[tid] = 0;
+  for (int i = tid; i < NPAIR * FC; i += 512) (&alive2[0][0])[i] = 0;
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const int i8 = tid + 512 * k;
@@ -763,21 +788,12 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
       rv[k][0] = rv[k][1] = R4[0];
     }
   }
-  // item i8 = (row i8 / 16, channels 8 (i8 % 16) ..): a thread sees the same eight channels in all its items (512 % 16 == 0)
-  f32x4 nz0 = {0.f, 0.f, 0.f, 0.f}, nz1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       mx = fmaxf(mx, fmaxf(fmaxf(rv[k][h][0], rv[k][h][1]), fmaxf(rv[k][h][2], rv[k][h][3])));
       mn = fminf(mn, fminf(fminf(rv[k][h][0], rv[k][h][1]), fminf(rv[k][h][2], rv[k][h][3])));
-    }
-    if (tid + 512 * k < R_ITEMS) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        nz0[e] = (rv[k][0][e] != 0.0f) ? 1.0f : nz0[e];
-        nz1[e] = (rv[k][1][e] != 0.0f) ? 1.0f : nz1[e];
-      }
     }
   }
 #pragma unroll
@@ -789,11 +805,21 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
     red[wave] = mx;
     red[NWAVE + wave] = mn;
   }
-  __syncthreads();   // (also: alive[] cleared)
+  __syncthreads();   // (also: alive2[][] cleared)
+  // item i8 = (row i8 / 16, channels 8 (i8 % 16) ..): flag the channels that are non-zero in the row's column-group pair
+  if (live_out != nullptr) {
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    if (nz0[e] != 0.0f) alive[8 * (tid & 15) + e] = 1;
-    if (nz1[e] != 0.0f) alive[8 * (tid & 15) + 4 + e] = 1;
+    for (int k = 0; k < 12; ++k) {
+      const int i8 = tid + 512 * k;
+      if (i8 < R_ITEMS) {
+        int* arow = &alive2[(i8 >> 4) / (2 * S)][8 * (i8 & 15)];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (rv[k][0][e] != 0.0f) arow[e] = 1;
+          if (rv[k][1][e] != 0.0f) arow[4 + e] = 1;
+        }
+      }
+    }
   }
   mx = red[0];
   mn = red[NWAVE];
@@ -809,16 +835,17 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
   // prepare and contraction kernels), plain order when the sweep does not compact (live_out NULL) or the volume has a negative value
   int ns = 4;
   if (live_out != nullptr) {
-    const int nlive = build_chan_list(alive, mn < 0.0f, chan_q, scr, tid);
-    ns = (nlive + 31) / 32;
-    ns = ns < 1 ? 1 : ns;
+    const int nlive = build_chan_list(alive2, mn < 0.0f, chan_q, scr, tid);
+    ns = 1;
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p) ns = chan_q[FC + p] > ns ? chan_q[FC + p] : ns;   // the largest walk: what is packed and gathered
     if (ver == 0) {
       if (tid == 0) {
         live_out[0] = (unsigned)ns;
         live_out[1] = (unsigned)nlive;
         live_out[2] = live_out[3] = 0u;
       }
-      if (tid < FC / 4) live_out[4 + tid] = reinterpret_cast<const unsigned*>(chan_q)[tid];
+      if (tid < FC / 4 + 4) live_out[4 + tid] = reinterpret_cast<const unsigned*>(chan_q)[tid];
     }
     // this workgroup's share of the W1 fragments gathered for the list (workgroups QV .. QV + QGW - 1 do nothing else)
     const int total8 = ns * S * 4 * 2 * 64;
@@ -900,7 +927,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
                                                              const _Float16* __restrict__ w1c) {
   constexpr int CHB = SPC * STEP_BYTES;          // window chunk
   constexpr int CPS = S / SPC;                   // chunks per channel slice
-  __shared__ __attribute__((aligned(16))) unsigned char chan_s[FC];   // channel of position 32 sc + 8 g + e of this pair's K walk
+  __shared__ __attribute__((aligned(16))) unsigned char chan_s[CHAN_BYTES];   // channel of position 32 sc + 8 g + e of this pair's K walk | slices per column-group pair
   constexpr int PFN = CHB / (512 * 16);          // DMA instructions per lane per chunk
   static_assert(S % SPC == 0 && CHB % (512 * 16) == 0 && CPS >= 3, "bad chunking");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -922,8 +949,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   // the K walk of this pair: the query's compacted channel list (ns slices of 32 live channels, W1 fragments gathered for them) when
   // the pair has no shift, the plain one (4 slices, the resident W1 fragments) otherwise -- workgroup-uniform
   const bool compact = live != nullptr && scales[2 * pair + 1][3] != 0.0f;
-  const int ns = __builtin_amdgcn_readfirstlane(load_chan_table(live, compact, chan_s, tid));
-  const int NCH = ns * CPS;                      // chunks per walk of K
+  (void)load_chan_table(live, compact, chan_s, tid);
   const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(compact ? w1c : w1p);
   unsigned char* lmine = lst + wave * LST_WAVE_BYTES;
   __syncthreads();   // channel table
@@ -959,8 +985,12 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   // result, depends neither on how the sweep is cut into launches nor on where the candidate stands in an index list -- a shard
   // of a pool whose first slot is a multiple of 32 (overlapnet_amd.distributed) reproduces the bits of the unsharded sweep
   const int slot = lidx ? lidx[pair] : pair0 + pair;
-  const int s0 = rot ? ((slot >> 3) & 3) % ns : 0;
+  const int s0b = rot ? ((slot >> 3) & 3) : 0;
   const int p_begin = part * (G / JBP) / nsplit, p_end = (part + 1) * (G / JBP) / nsplit;
+  // slices walked by a pass: those of its column-group pair (4 for a pair that is not compacted); the walk starts at slice s0b mod that
+#define OVN_NS_OF(PASS) ((int)__builtin_amdgcn_readfirstlane((int)chan_s[FC + ((JBP == 2) ? (PASS) : ((PASS) >> 1))]))
+  int ns = OVN_NS_OF(p_begin);
+  int s0 = s0b % ns;
   int cur = 0, rcur = 0;
   int chunk = CPS * s0;
   OVN_DMA_W(chunk, 0)
@@ -970,6 +1000,8 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 
   u32x4 la[3][2];   // this lane's words of the current L slice
   for (int pass = p_begin; pass < p_end; ++pass) {
+    const int ns_n = (pass + 1 < p_end) ? OVN_NS_OF(pass + 1) : ns;   // the next pass's walk: where the prefetches at the end of this one go
+    const int s0_n = s0b % ns_n;
     f32x4 acc[JBP][3][4];
 #pragma unroll
     for (int j = 0; j < JBP; ++j)
@@ -993,11 +1025,12 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
           }
       }
       const unsigned* rsl = rb + sl * (S * 32);
+      const int sl_n = (q4 + 1 == ns) ? s0_n : ((sl + 1 == ns) ? 0 : sl + 1);   // the slice walked after this one
 #pragma unroll 1
       for (int c5 = 0; c5 < CPS; ++c5) {
-        const int nxt = (chunk + 1 == NCH) ? 0 : chunk + 1;
+        const int nxt = (c5 + 1 < CPS) ? chunk + 1 : CPS * sl_n;
         if (!(ABL & 2)) OVN_DMA_W((ABL & 64) ? 0 : nxt, cur ^ 1)
-        if (!(ABL & 8) && c5 == 1) OVN_DMA_L((sl + 1 == ns) ? 0 : sl + 1)        // this wave read its la registers a barrier ago
+        if (!(ABL & 8) && c5 == 1) OVN_DMA_L(sl_n)                               // this wave read its la registers a barrier ago
         if (!(ABL & 16) && c5 == 2 && q4 == 0 && pass + 1 < p_end) OVN_DMA_R(pass + 1, rcur ^ 1)
         // operand fragments of step h+1 are read from LDS while step h's MFMAs run (two register sets, static indices)
         u32x4 rw[2][4];
@@ -1071,7 +1104,10 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
         }
     }
     rcur ^= 1;
+    ns = ns_n;
+    s0 = s0_n;
   }
+#undef OVN_NS_OF
 #undef OVN_DMA_L
 #undef OVN_DMA_W
 #undef OVN_DMA_R
