@@ -1128,6 +1128,26 @@ def test_dead_channel_compaction_of_the_query(engines):
             fv = cands[:8].reshape(8, 1, 360, 128).astype(np.float64)
             o_ov, o_yaw, o_lg, _ = O.heads_forward(fv, np.repeat(q.reshape(1, 1, 360, 128).astype(np.float64), 8, axis=0), w)
             assert np.max(np.abs(ov1[:8] - o_ov)) <= 1e-4 and np.max(np.abs(lg1[:8] - o_lg)) <= 1e-3 * (1 + np.max(np.abs(o_lg)))
+    # channels that are alive only in SOME column-group pairs (the list is ordered by that count and every pass walks only up to its
+    # own last live position): random patterns, incl. pairs without a single live channel
+    for trial in range(6):
+        q = np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)
+        keep = rng.random((12, 128)) < rng.choice([0.15, 0.5, 0.85])
+        keep[:, rng.permutation(128)[:20]] = False
+        if trial == 5:
+            keep[3] = False
+            keep[11] = False
+        q[0] *= np.repeat(keep, 30, axis=0)
+        lg1, ov1, yw1 = sweep(q, True)
+        lg0, ov0, yw0 = sweep(q, False)
+        lgn, _, ywn = sweep(q, True, use_cache=False)
+        assert np.array_equal(lg1, lgn) and np.array_equal(yw1, ywn), trial
+        assert np.array_equal(yw1, yw0) and np.max(np.abs(lg1 - lg0)) <= 2e-5 * (1 + np.max(np.abs(lg0))), trial
+        # a sweep of 3 candidates (half-pass workgroups) has the bits of the big one
+        e.set_head_compaction(True)
+        dq = torch.from_numpy(q).cuda()
+        r3 = e.heads(dc[:3].contiguous(), dq, spec_l=spec[:3].contiguous(), spec_r=e.spectrum(dq), dcache_l=cache[:3].contiguous(), want_logit=True)
+        assert np.array_equal(r3["logit"].cpu().numpy(), lg1[:3]), trial
     # a negative value anywhere in the query: the pair needs a shift, nothing is dropped -> the bits of the uncompacted walk
     q = np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)
     q[:, :, :40] = 0
