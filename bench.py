@@ -609,6 +609,10 @@ def main():
         "config": {"workload": workload, "mode": args.mode, "pairs_per_step": n_total, "pairs_per_rank": P, "channels": C,
                    "weights": "seeded synthetic (no trained weights ship)", "head_precision": args.head_precision,
                    "leg_precision": leg_precision, "correlation_head": args.corr,
+                   "delta_contraction": ("all 128 feature channels (ovn_set_head_compaction 0)" if args.no_compaction else
+                                         "exact dead-channel compaction: channels that are zero in all columns of the query (of a column-group "
+                                         "pair) are dropped from K -- roofline.k_walk_frac of the 128 walked, same results to fp32 rounding; "
+                                         "dense_walk = the same step without it"),
                    "query_leg": ("step k + 1's query leg + spectrum on a second context / stream beside step k's head kernels "
                                  "(engine.QueryAhead; one leg and one head sweep enqueued per step)" if qa is not None
                                  else "on the heads' stream, in front of them"),
