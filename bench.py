@@ -312,6 +312,63 @@ def golden_accuracy(ov, yw, wset="glorot"):
                               "(oracle outputs: tests/golden/parity_sweep_%s.npz)" % wset}
 
 
+def trained_like_record(C, P, dev, pool_imgs, query_ring, query_img, steps, flop_per_pair, peak):
+    """The timed warm step (streamed queries, 1-vs-P, cached candidates) under the trained-like weight set, with and without the
+    dead-channel compaction; accuracy of query 0 over all pairs against the committed fp64 oracle outputs of that set."""
+    from overlapnet_amd.engine import QueryAhead
+    wt = S.make_trained_like_weights(C)
+    e2 = OvnEngine(64, 900, C, device=dev.index)
+    e2.load_weights(wt, S.REFERENCE_MODEL_CFG)
+    qa2 = None
+    try:
+        cands = torch.empty((P, 360, 128), dtype=torch.float32, device=dev)
+        for s0 in range(0, P, 128):
+            e2.leg(pool_imgs[s0:s0 + 128], out=cands[s0:s0 + 128])
+        spec, dc = e2.spectrum(cands), e2.delta_cache(cands)
+        qa2 = QueryAhead(e2, wt, S.REFERENCE_MODEL_CFG)
+        pos = [0]
+
+        def nxt():
+            pos[0] = (pos[0] + 1) % len(query_ring)
+            return query_ring[pos[0]]
+        qa2.submit(nxt())
+
+        def step():
+            qa2.submit(nxt())
+            fv, sp = qa2.take()
+            r = e2.heads(cands, fv, spec_l=spec, spec_r=sp, dcache_l=dc)
+            return r["overlap"], r["yaw"]
+        rec = {"weights": "tools/synthetic.make_trained_like_weights (leg gain 1.6, O(1) biases, Dense gain 10: logits -20 .. 18)"}
+        for name, on in (("compacted", True), ("dense_walk", False)):
+            e2.set_head_compaction(on)
+            el, pr, _ = timed(step, 2, steps, e2, False, dev, side_eng=qa2.side)
+            c12 = pr["delta_c12"][0] / max(pr["delta_c12"][1], 1)
+            rec[name] = {"value": P * steps / el, "unit": "pairs/s", "ms_per_step": 1e3 * el / steps, "delta_c12_ms": c12,
+                         "frac": flop_per_pair * P / (c12 * 1e-3) / 1e12 / peak}
+        e2.set_head_compaction(True)
+        walks, lives = [], []
+        for qi in query_ring:
+            fq = e2.leg(qi)
+            e2.heads(cands[:32], fq, spec_l=spec[:32], spec_r=e2.spectrum(fq), dcache_l=dc[:32])
+            st = e2.head_walk_stats()
+            walks.append(st["k_walk_frac"])
+            lives.append(st["live_channels"])
+        rec["k_walk_frac"] = sum(walks) / len(walks)
+        rec["k_walk_by_query"] = {"live_channels": lives, "k_walk_frac": walks}
+        qa2.take()
+        fq = e2.leg(query_img)
+        r = e2.heads(cands, fq, spec_l=spec, spec_r=e2.spectrum(fq), dcache_l=dc)
+        torch.cuda.synchronize()
+        if P == 1024 and C == 4 and os.path.isfile(os.path.join(ROOT, "tests", "golden", "parity_sweep_trained_like.npz")):
+            ga = golden_accuracy(r["overlap"].float().cpu().numpy(), r["yaw"].cpu().numpy(), "trained_like")
+            rec.update({k: ga[k] for k in ("overlap_mae_vs_oracle", "overlap_maxerr_vs_oracle", "yaw_exact_rate", "accuracy_pairs")})
+        return rec
+    finally:
+        if qa2 is not None:
+            qa2.close()
+        e2.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -443,10 +500,13 @@ def main():
                 pool_imgs[s:s + timg.shape[0]].copy_(timg)
             eng.leg(timg, out=cands[s:s + timg.shape[0]])
     query_img = torch.from_numpy(S.sweep_query_image(C, fx)).to(dev)
-    # the stream of queries of the warm step: the query scan and seven column-rolled copies of it, taken in turn (every step sees
-    # another query image: no step finds its query's lines in L2 / the Infinity Cache because the previous step left them there);
-    # the accuracy block evaluates query 0 in a step of its own
-    query_ring = [query_img] + [torch.roll(query_img, 113 * k, dims=2).contiguous() for k in range(1, 8)]
+    # the stream of queries of the warm step: EIGHT DIFFERENT SCANS taken in turn -- the query scan and seven scans drawn like the pool's
+    # candidates (both shipped scans, other column shifts, their own depth noise; another seed than the pool's), each through the leg
+    # inside its step.  Their live-channel counts / K walks are reported per query (roofline.k_walk_by_query); the accuracy block
+    # evaluates query 0 in a step of its own
+    ring_np = S.candidate_images(8, C, seed=4321, fixture=fx)[1:]
+    query_ring = [query_img] + [torch.from_numpy(np.ascontiguousarray(np.roll(ring_np[k], 113 * (k + 1), axis=1))[None]).to(dev)
+                                for k in range(7)]
     ring_pos = [0]
 
     def next_query():
@@ -581,14 +641,17 @@ def main():
     achieved = flop_per_pair * launch_pairs / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
     # dead-channel compaction (ovn_set_head_compaction): the contraction walks ceil(live / 32) of the 4 channel slices, where `live`
     # counts the channels that are non-zero somewhere in the QUERY's 360 columns -- measured here on the queries of the timed stream
-    live_counts, slices = [], []
-    if args.mode == "warm" and args.head_precision == "f16x3":
+    # (read back from the library after an untimed sweep per query: ovn_head_walk_stats -- slices walked by each of the 12 passes)
+    live_counts, walks = [], []
+    if args.mode == "warm" and args.head_precision == "f16x3" and spectral and P > 0:
+        n_w = min(P, 32)
         for qi in query_ring:
-            fq = eng.leg(qi)[0]
-            nl = int((fq != 0).any(dim=0).sum().item())
-            live_counts.append(nl)
-            slices.append(4 if (args.no_compaction or float(fq.min().item()) < 0) else max(1, -(-nl // 32)))
-    walk_frac = (sum(slices) / (4.0 * len(slices))) if slices else 1.0
+            fq = eng.leg(qi)
+            eng.heads(cands[:n_w], fq, spec_l=cand_spec[:n_w], spec_r=eng.spectrum(fq), dcache_l=cand_dc[:n_w] if cand_dc is not None else None)
+            st = eng.head_walk_stats()
+            live_counts.append(st["live_channels"])
+            walks.append(st["k_walk_frac"])
+    walk_frac = (sum(walks) / len(walks)) if walks else 1.0
     mfma_per_alg = (3.0 * walk_frac) if args.head_precision == "f16x3" else 1.0
     if strong:
         workload = ("1-vs-%d synthetic candidate pool sharded over %d rank(s) in contiguous blocks (BASELINE configs[3]; warm: 1 query "
@@ -625,6 +688,9 @@ def main():
                      "frac_executed": mfma_per_alg * achieved / peak,
                      "query_live_channels": (sum(live_counts) / len(live_counts)) if live_counts else None,
                      "k_walk_frac": walk_frac,
+                     "k_walk_by_query": {"live_channels": live_counts, "k_walk_frac": walks,
+                                         "note": "the eight scans of the timed query stream; k_walk_frac = slices of 32 channels walked by "
+                                                 "the 12 passes of the contraction / 48 (ovn_head_walk_stats)"} if walks else None,
                      "delta_total_ms": sum(prof[k][0] / max(prof[k][1], 1) for k in ("delta_prep", "delta_c12", "delta_c2") if k in prof),
                      "note": rl_note + ("; the next query's leg kernels run on a second stream beside this kernel (QueryAhead): its event "
                                         "time includes the CUs they take at its round boundaries" if qa is not None else "")},
@@ -721,9 +787,16 @@ def main():
                 e0b, p0b, r0b = timed(step_warm, 2, sub_steps, eng, False, dev, side_eng=qa.side if qa is not None else None)
             finally:
                 eng.set_head_compaction(True)
+            c12_dense = p0b["delta_c12"][0] / max(p0b["delta_c12"][1], 1)
             out["dense_walk"] = {"value": P * sub_steps / e0b, "unit": "pairs/s", "ms_per_step": 1e3 * e0b / sub_steps, "steps": sub_steps,
-                                 "delta_c12_ms": p0b["delta_c12"][0] / max(p0b["delta_c12"][1], 1),
+                                 "delta_c12_ms": c12_dense,
+                                 "frac": flop_per_pair * P / (c12_dense * 1e-3) / 1e12 / peak,
                                  "step": "the timed step with ovn_set_head_compaction(0): every pair walks all 128 feature channels"}
+        # (0c) the SECOND weight set (trained-like dynamic range, tools/synthetic.make_trained_like_weights: the set the parity sweep
+        #      checks pair by pair) through the same streamed step: its own engine, pool features, spectra, Delta rows and query-ahead
+        #      context; compaction on, then off.  What the compaction buys depends on the query's dead channels, i.e. on the weights.
+        if args.head_precision == "f16x3" and spectral and pool_imgs is not None and not args.no_compaction:
+            out["trained_like"] = trained_like_record(C, P, dev, pool_imgs, query_ring, query_img, sub_steps, flop_per_pair, peak)
         # (1) everything on the fp32 matrix cores, direct correlation form
         eng.set_head_precision("f32")
         eng.set_leg_precision("f32")
@@ -869,13 +942,23 @@ def main():
     # in THIS run
     rl0 = out["roofline"]
     rl0["traffic"] = t_bytes
-    rl = {k: rl0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "frac_executed", "k_walk_frac")}
+    rl = {k: rl0[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac")}
 
     def sub(name, key, as_name):
         if name in out and key in out[name]:
             rl[as_name] = out[name][key]
+    # `frac` counts the ALGORITHMIC flops of a sweep whose K walk skipped the query's dead channels (k_walk_frac of the 128 walked);
+    # `frac_dense` is the same kernel walking all 128 -- what ANY query is guaranteed.  Both, for both weight sets.
+    sub("dense_walk", "frac", "frac_dense")
+    for k in ("traffic", "frac_executed", "k_walk_frac"):
+        rl[k] = rl0[k]
     sub("dense_walk", "value", "dense_walk_pairs_per_s")
-    rl["step_pairs_per_s"] = out["value"]
+    if "trained_like" in out:
+        tl = out["trained_like"]
+        rl["value_trained_like"] = tl["compacted"]["value"]
+        rl["frac_trained_like"] = tl["compacted"]["frac"]
+        rl["frac_dense_trained_like"] = tl["dense_walk"]["frac"]
+        rl["k_walk_frac_trained_like"] = tl["k_walk_frac"]
 
     sub("cold", "value", "cold_pairs_per_s")
     sub("cold", "leg_scans_per_s", "cold_leg_scans_per_s")
@@ -883,22 +966,29 @@ def main():
     sub("fullstack", "value", "fullstack_pairs_per_s")
     sub("fullstack", "projection_scans_per_s", "fullstack_projection_scans_per_s")
     sub("fullstack", "projection_frac_of_hbm_peak", "projection_frac_of_hbm_peak")
-    sub("fullstack", "overlap_maxerr_vs_oracle", "fullstack_overlap_maxerr_vs_oracle")
     if "overlap_maxerr_vs_oracle" in out:
         rl["overlap_maxerr_vs_oracle"] = out["overlap_maxerr_vs_oracle"]
     if prof.get("corr_spectral", (0, 0))[1] and spectral:
         ms_in = prof["corr_spectral"][0] / prof["corr_spectral"][1]
         rl["corr_in_step_frac_of_hbm_peak"] = P * CAND_BYTES_PER_PAIR / (ms_in * 1e-3) / PEAK_HBM_BPS
-    if "corr_head" in out and "n16384" in out["corr_head"]:
-        rl["corr_n16384_frac_of_hbm_peak"] = out["corr_head"]["n16384"]["frac_of_8TBps"]
     if "latency" in out:
         rec = out["latency"].get("n1", {})
         if "ms_per_query" in rec:
             rl["latency_n1_ms"] = rec["ms_per_query"]
+    # ---- (beyond the driver's 24 keys: kept in the line itself) ----
+    if "latency" in out:
+        rec = out["latency"].get("n1", {})
         if "ms_per_query_streamed" in rec:
             rl["latency_n1_streamed_ms"] = rec["ms_per_query_streamed"]
+    rl["step_pairs_per_s"] = out["value"]
+    sub("fullstack", "overlap_maxerr_vs_oracle", "fullstack_overlap_maxerr_vs_oracle")
+    if "corr_head" in out and "n16384" in out["corr_head"]:
+        rl["corr_n16384_frac_of_hbm_peak"] = out["corr_head"]["n16384"]["frac_of_8TBps"]
+    if "trained_like" in out:
+        rl["dense_walk_trained_like_pairs_per_s"] = out["trained_like"]["dense_walk"]["value"]
+        if "overlap_maxerr_vs_oracle" in out["trained_like"]:
+            rl["overlap_maxerr_vs_oracle_trained_like"] = out["trained_like"]["overlap_maxerr_vs_oracle"]
     rl["traffic_from"] = (t_src.get("source") or "none") if isinstance(t_src, dict) else str(t_src)
-    # ---- (beyond the driver's 24 keys: kept in the line itself) ----
     if args.head_precision == "f16x3":
         # executed MFMA rate against what a bare MFMA loop sustains on real operands (a committed measurement, not this run's)
         rl["executed_frac_of_sustained_mfma_rate"] = mfma_per_alg * rl0["achieved"] / SUSTAINED_16BIT_MFMA_TFLOPS

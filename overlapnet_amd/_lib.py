@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libovn_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _f32p = C.POINTER(C.c_float)
 _i32p = C.POINTER(C.c_int32)
@@ -55,6 +55,7 @@ SIGNATURES = {
     "ovn_profile_end": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "ovn_debug_conv": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "ovn_debug_head_activations": (C.c_int, [_vp, C.c_int64, _vp, _vp, _vp]),
+    "ovn_head_walk_stats": (C.c_int, [_vp, _i32p, _vp]),
     "ovn_workspace_bytes": (C.c_int64, [_vp]),
     "ovn_comm_unique_id": (C.c_int, [_vp]),
     "ovn_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),

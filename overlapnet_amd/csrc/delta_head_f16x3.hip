@@ -1315,6 +1315,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   // 1-vs-N sweeps (one query for all pairs): the query's live-channel list and the W1 fragments gathered for it; indexed pairs walk
   // the plain K (every pair has its own right volume)
   const unsigned* live = (ridx || !ctx->head_compact) ? nullptr : live_buf;
+  ctx->dbg_live = live;   // ovn_head_walk_stats: the K walk of the most recent sweep (its last chunk)
   *o2max_out = o2max;
   const int nsplit = pick_nsplit(n);   // 24: half-passes (one column group per workgroup), chosen for <= 10 pairs
   {
@@ -1381,6 +1382,26 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
                          reinterpret_cast<const _Float16*>(ctx->w2p_h), desc, scales, o2, o2max, 1.0f);
   }
   OVN_HIP_CHECK(hipGetLastError());
+  return OVN_OK;
+}
+
+// ovn_head_walk_stats: {largest slice count, live channels, slices of passes 0 .. 11, compacted?, 0} of the most recent sweep
+int ovn_delta_walk_stats(ovn_ctx* ctx, int32_t* out16, hipStream_t stream) {
+  for (int i = 0; i < 16; ++i) out16[i] = 0;
+  if (ctx->dbg_live == nullptr) {   // indexed pairs, fp32 mode, compaction off: every pass walks the 4 slices of all 128 channels
+    out16[0] = 4;
+    out16[1] = FC;
+    for (int p = 0; p < NPAIR; ++p) out16[2 + p] = 4;
+    return OVN_OK;
+  }
+  unsigned h[LIVE_WORDS];
+  OVN_HIP_CHECK(hipMemcpyAsync(h, ctx->dbg_live, sizeof(h), hipMemcpyDeviceToHost, stream));
+  OVN_HIP_CHECK(hipStreamSynchronize(stream));
+  out16[0] = (int32_t)h[0];
+  out16[1] = (int32_t)h[1];
+  const unsigned char* nsp = reinterpret_cast<const unsigned char*>(h + 4) + FC;
+  for (int p = 0; p < NPAIR; ++p) out16[2 + p] = nsp[p];
+  out16[14] = 1;
   return OVN_OK;
 }
 

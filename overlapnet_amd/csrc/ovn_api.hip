@@ -800,6 +800,12 @@ int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3
   return OVN_OK;
 }
 
+int ovn_head_walk_stats(ovn_ctx* ctx, int32_t* out16_host, void* stream) {
+  OVN_REQUIRE(ctx && out16_host, OVN_ERR_ARG, "ovn_head_walk_stats: NULL argument");
+  OVN_ON_DEVICE(ctx->device);
+  return ovn_delta_walk_stats(ctx, out16_host, (hipStream_t)stream);
+}
+
 int64_t ovn_workspace_bytes(ovn_ctx* ctx) { return ctx ? (int64_t)ctx->ws_bytes : 0; }
 
 int ovn_selftest(ovn_ctx* ctx) {

@@ -198,6 +198,7 @@ struct ovn_ctx {
   float* dbg_partial = nullptr;
   const unsigned* dbg_o2max = nullptr;
   int64_t dbg_n = 0;
+  const unsigned* dbg_live = nullptr;   // live-channel list of the most recent f16x3 Delta sweep (NULL: it walked all 128 channels)
 };
 
 // kernel classes reported by ovn_profile_end
@@ -257,6 +258,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
                                 int pair0 = 0,    // pair0: index of the call's first pair in the sweep (rotation of the K walks)
                                 const float* dcache_l = nullptr);   // Delta cache rows of the left pool (ovn_delta_cache), 1-vs-N only
 int ovn_delta_cache_forward(ovn_ctx* ctx, const float* feats, int n, float* cache, hipStream_t stream);
+int ovn_delta_walk_stats(ovn_ctx* ctx, int32_t* out16, hipStream_t stream);
 
 // delta_head_generic.hip: the Delta head for any conv1size (fp32, generality path)
 size_t ovn_delta_generic_pair_bytes(int G);

@@ -442,6 +442,15 @@ class OvnEngine:
         _lib.check(self.lib.ovn_set_head_compaction(self._h, int(bool(on))), "ovn_set_head_compaction")
         self.head_compaction = bool(on)
 
+    def head_walk_stats(self) -> dict:
+        """The K walk the Delta head's contraction took in the most recent 1-vs-N sweep (`ovn_head_walk_stats`): slices of 32 channels
+        walked by each of its 12 passes, the query's live channels, and the fraction of the 128-channel walk that is."""
+        out = (C.c_int32 * 16)()
+        _lib.check(self.lib.ovn_head_walk_stats(self._h, out, self._stream()), "ovn_head_walk_stats")
+        spp = [int(out[2 + p]) for p in range(12)]
+        return {"max_slices": int(out[0]), "live_channels": int(out[1]), "slices_per_pass": spp, "compacted": bool(out[14]),
+                "k_walk_frac": sum(spp) / 48.0}
+
     def set_projection_trig(self, mode: str) -> None:
         """Which float32 `np.arctan2` / `np.arcsin` (utils.py:86-87) `project` reproduces: 'numpy_avx512' (default: NumPy >= 1.22 on an
         AVX512_SKX x86-64 host -- Intel SVML, bit for bit; the machine the reference's shipped .npy files were made on) or 'rounded'

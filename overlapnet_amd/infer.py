@@ -321,8 +321,14 @@ class Infer():
       ids = np.arange(vols.shape[0])
       mine = ids[D.frame_owner(ids, self._world) == self._rank]
       slots = D.frame_slot(mine, self._world)
-      for k in np.argsort(slots, kind='stable'):       # increasing slot order; runs of consecutive slots go in one copy
-        cache.put_device(int(slots[k]), torch.from_numpy(vols[mine[k]:mine[k] + 1]).to(self.engine.device))
+      order = np.argsort(slots, kind='stable')         # increasing slot order
+      mine, slots = mine[order], slots[order]
+      # ONE host-to-device copy of everything this rank owns, then one put_device (copy + batched spectrum / Delta rows) per RUN of
+      # consecutive slots: a rank's slots are contiguous except where a frame of the last, incomplete round is still missing
+      dev_vols = torch.from_numpy(np.ascontiguousarray(vols[mine])).to(self.engine.device)
+      starts = np.concatenate([[0], np.nonzero(np.diff(slots) != 1)[0] + 1, [len(slots)]])
+      for a, b in zip(starts[:-1], starts[1:]):
+        cache.put_device(int(slots[a]), dev_vols[a:b])
     elif vols.shape[0]:
       cache.extend_device(torch.from_numpy(vols).to(self.engine.device))
     self._feature_volumes = cache
@@ -672,6 +678,26 @@ class Infer():
     if bad:
       raise Exception('sharded Infer: the local work of rank(s) %s failed (see their own exception); the query is void on every rank' % bad)
 
+  def _frame_done(self, statuses, local_error):
+    """After the status exchange of a sharded call: the frame counts as fed -- `_n_frames` advances, on EVERY rank -- only when no
+    rank's local work failed.  Otherwise every rank raises and the frame id stays the next expected one: the owner's slot may be
+    unwritten (its leg failed), so nothing may refer to it; the caller repairs the cause and feeds the SAME frame again
+    (`put_device` overwrites the slot where it was written)."""
+    if local_error is None and not np.any(np.asarray(statuses) != 0):
+      self._n_frames += 1
+      return
+    self._drop_ahead()
+    self._ahead = None
+    self._raise_rank_failure(statuses, local_error)
+
+  def _agree_frame_cached(self, local_error):
+    """A sharded call with an EMPTY reference list (the first frames of demo3) has no scores to exchange, but the ranks must still
+    agree on whether the current frame was cached: one 16-byte record per rank, word 3 < 0 = this rank's local work failed."""
+    from . import distributed as D
+    rec = torch.tensor([-1, 0, 0, -1 if local_error is not None else 0], dtype=torch.int32, device=self.engine.device)
+    recs = D.allgather_records(rec, self._group)
+    self._frame_done((recs.reshape(-1, 4)[:, 3] < 0).numpy(), local_error)
+
   def _infer_multiple_sharded(self, current_frame_id, reference_frame_id):
     from . import distributed as D
     fid = self._check_sharded_frame(current_frame_id)
@@ -684,17 +710,17 @@ class Infer():
         r = self._local_heads_sharded(ref, mine, q_fv, q_spec)
     except Exception as e:                    # noqa: BLE001 -- carried to every rank in the payload below
       err = e
-    self._n_frames += 1
-    if len(ref) == 0:
-      if err is not None:
-        raise err
+    if len(ref) == 0:                         # no scores to exchange: the ranks still agree on whether the frame was cached
+      self._agree_frame_cached(err)
+      if err is None:
+        self._start_ahead(current_frame_id)
       return None
     if err is None:
       self._start_ahead(current_frame_id)
     ov = r["overlap"] if r is not None else torch.empty(0, dtype=torch.float32, device=dev)
     yw = r["yaw"] if r is not None else torch.empty(0, dtype=torch.int32, device=dev)
     ov_all, yaw_all, statuses = D.allgather_by_owner(ov, yw, owner, self._group, status=0 if err is None else 1)
-    self._raise_rank_failure(statuses, err)
+    self._frame_done(statuses, err)
     res = torch.stack([ov_all.view(torch.int32), yaw_all]).cpu().numpy()      # ONE device-to-host copy for both
     overlap = res[0].view(np.float32).reshape(-1, 1)
     return overlap.squeeze(), res[1].astype(np.int64)
@@ -714,10 +740,10 @@ class Infer():
           rec = self.engine.best_match(r["overlap"], r["yaw"], overlap_thres, ids=pos)
     except Exception as e:                    # noqa: BLE001
       err = e
-    self._n_frames += 1
     if len(ref) == 0:
-      if err is not None:
-        raise err
+      self._agree_frame_cached(err)
+      if err is None:
+        self._start_ahead(current_frame_id)
       return None
     if err is not None:
       rec = torch.tensor([-1, 0, 0, -1], dtype=torch.int32, device=self.engine.device)      # word 3 < 0: this rank failed
@@ -726,7 +752,7 @@ class Infer():
     if err is None:
       self._start_ahead(current_frame_id)
     recs = D.allgather_records(rec, self._group)
-    self._raise_rank_failure((recs.reshape(-1, 4)[:, 3] < 0).numpy(), err)
+    self._frame_done((recs.reshape(-1, 4)[:, 3] < 0).numpy(), err)
     got = decode_match(D.merge_matches_by_position(recs))
     if got is None:
       return None

@@ -99,16 +99,21 @@ def infer_api(work):
         ref.infer_multiple(0, [])
         b1 = ref.infer_multiple(1, [0])
         report["reset_ok"] = bool(a0 is None and np.array_equal(a1[0], b1[0]) and np.array_equal(a1[1], b1[1]) and a1[0].shape == ())
-    # a failure of ONE rank's local work (here: rank 1's leg raises) reaches every rank through the collective's payload: both
-    # raise, nobody is left waiting in the all-gather
+    # a failure of ONE rank's local work (here: the leg of rank 1, the OWNER of frame 3, raises) reaches every rank through the
+    # collective's payload: both raise, nobody is left waiting in the all-gather -- also when the reference list is empty
+    # (no scores to exchange: a 16-byte status record instead) -- and the frame does NOT count as fed on any rank: its
+    # owner's slot was never written, so the same frame is fed again once the cause is repaired, and later frames may refer to it
+    a2 = sh.infer_multiple(2, [0, 1])
+    good_leg = sh._leg_device
     if rank == 1:
         def boom(names):
             raise Exception("Could not read depth image (simulated, rank 1 only)")
         sh._leg_device = boom
     sh._stream_ahead = False
     sh._drop_ahead()
-    raised = [None, None]
-    for k, call in enumerate((lambda: sh.infer_multiple(2, [0, 1]), lambda: sh.infer_best_match(3, [0, 1], 0.3))):
+    raised = [None, None, None]
+    for k, call in enumerate((lambda: sh.infer_multiple(3, [0, 1, 2]), lambda: sh.infer_best_match(3, [0, 1, 2], 0.3),
+                              lambda: sh.infer_multiple(3, []))):
         try:
             call()
             raised[k] = "returned"
@@ -117,6 +122,12 @@ def infer_api(work):
     both = [None, None]
     dist.all_gather_object(both, raised)
     report["one_rank_failure"] = both
+    sh._leg_device = good_leg
+    a3 = sh.infer_multiple(3, [0, 1, 2])            # the same frame again
+    a4 = sh.infer_multiple(4, [0, 1, 2, 3])         # ... and a frame that refers to it
+    if rank == 0:
+        b2, b3, b4 = ref.infer_multiple(2, [0, 1]), ref.infer_multiple(3, [0, 1, 2]), ref.infer_multiple(4, [0, 1, 2, 3])
+        report["retry_ok"] = bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in ((a2, b2), (a3, b3), (a4, b4))))
     sh.close()
     if ref is not None:
         ref.close()

@@ -1130,19 +1130,42 @@ def test_dead_channel_compaction_of_the_query(engines):
             assert np.max(np.abs(ov1[:8] - o_ov)) <= 1e-4 and np.max(np.abs(lg1[:8] - o_lg)) <= 1e-3 * (1 + np.max(np.abs(o_lg)))
     # channels that are alive only in SOME column-group pairs (the list is ordered by that count and every pass walks only up to its
     # own last live position): random patterns, incl. pairs without a single live channel
-    for trial in range(6):
+    # Every pattern is ALSO compared with the fp64 oracle directly (16 pairs each, on the cache-row route `Infer` and bench.py take):
+    # against compaction-off alone the HIP path would only be checked against itself.
+    NOR = 16
+    fv_or = cands[:NOR].reshape(NOR, 1, 360, 128).astype(np.float64)
+    for trial in range(7):
         q = np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)
-        keep = rng.random((12, 128)) < rng.choice([0.15, 0.5, 0.85])
-        keep[:, rng.permutation(128)[:20]] = False
-        if trial == 5:
-            keep[3] = False
-            keep[11] = False
+        if trial < 6:
+            keep = rng.random((12, 128)) < rng.choice([0.15, 0.5, 0.85])
+            keep[:, rng.permutation(128)[:20]] = False
+            if trial == 5:
+                keep[3] = False
+                keep[11] = False
+        else:
+            # nested live sets: 20 channels alive in every column-group pair, 30 more from pair 3 on, 30 more from pair 6 on, 30 more
+            # from pair 9 on -> the list orders them by that count and passes 0-2 / 3-5 / 6-8 / 9-11 walk 1 / 2 / 3 / 4 slices
+            perm = rng.permutation(128)
+            keep = np.zeros((12, 128), bool)
+            keep[:, perm[:20]] = True
+            keep[3:, perm[20:50]] = True
+            keep[6:, perm[50:80]] = True
+            keep[9:, perm[80:110]] = True
+            q[0, :, perm[:110]] += 0.01      # every kept channel really is alive in each of its pairs
         q[0] *= np.repeat(keep, 30, axis=0)
         lg1, ov1, yw1 = sweep(q, True)
         lg0, ov0, yw0 = sweep(q, False)
         lgn, _, ywn = sweep(q, True, use_cache=False)
         assert np.array_equal(lg1, lgn) and np.array_equal(yw1, ywn), trial
         assert np.array_equal(yw1, yw0) and np.max(np.abs(lg1 - lg0)) <= 2e-5 * (1 + np.max(np.abs(lg0))), trial
+        o_ov, o_yaw, o_lg, _ = O.heads_forward(fv_or, np.repeat(q.reshape(1, 1, 360, 128).astype(np.float64), NOR, axis=0), w)
+        assert np.max(np.abs(ov1[:NOR] - o_ov)) <= 1e-4, (trial, float(np.max(np.abs(ov1[:NOR] - o_ov))))
+        assert np.max(np.abs(lg1[:NOR] - o_lg) / (1 + np.abs(o_lg))) <= 1e-3, trial
+        assert np.array_equal(yw1[:NOR], o_yaw), trial
+        if trial == 6:
+            sweep(q, True)
+            st = e.head_walk_stats()          # the walk the kernel really took (ovn_head_walk_stats)
+            assert st["compacted"] and st["slices_per_pass"] == [1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4] and st["live_channels"] == 110, st
         # a sweep of 3 candidates (half-pass workgroups) has the bits of the big one
         e.set_head_compaction(True)
         dq = torch.from_numpy(q).cuda()

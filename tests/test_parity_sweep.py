@@ -29,7 +29,10 @@ CFG = S.REFERENCE_MODEL_CFG
 CASES = [("glorot", 4, 1024), ("trained_like", 4, 1024), ("trained_like", 1, 128), ("trained_like", 5, 128), ("trained_like", 4, 4096)]
 
 # (name, leg arithmetic, head arithmetic, correlation form); the first row is what bench.py and `Infer` run by default
+# "default" prepares every pair in scratch; "default_cached" is the route bench.py and `Infer` take: the candidates' Delta cache rows
+# (ovn_delta_cache) + the query's shared block, with the dead-channel compaction of the query (both routes vs the oracle)
 MODES = [("default", None, None, "spectral"),
+         ("default_cached", None, None, "spectral_cached"),
          ("all_f32", "f32", "f32", "direct")]
 
 
@@ -92,6 +95,9 @@ def test_sweep_every_pair_against_oracle(wset, C, POOL):
             qfv = eng.leg(qimg)
             if corr_form == "spectral":
                 r = eng.heads(cands, qfv, spec_l=eng.spectrum(cands), spec_r=eng.spectrum(qfv), want_logit=True)
+            elif corr_form == "spectral_cached":
+                r = eng.heads(cands, qfv, spec_l=eng.spectrum(cands), spec_r=eng.spectrum(qfv), want_logit=True,
+                              dcache_l=eng.delta_cache(cands))
             else:
                 r = eng.heads(cands, qfv, want_logit=True)
             torch.cuda.synchronize()
@@ -99,6 +105,7 @@ def test_sweep_every_pair_against_oracle(wset, C, POOL):
             d_ov, d_lg = ov - g["overlap"], lg - g["logit"]
             bad = np.nonzero(yaw != g["yaw"])[0]
             rec = {"leg": eng.leg_precision, "head": eng.head_precision, "corr": corr_form, "pairs": POOL,
+                   "k_walk": eng.head_walk_stats() if head_p is None else None,
                    "abs_d_overlap": _stats(d_ov), "abs_d_logit": _stats(d_lg),
                    "feature_sum_rel_err_max": float(np.max(np.abs(cands.double().sum(dim=(1, 2)).cpu().numpy() - g["feat_sum"])
                                                            / np.abs(g["feat_sum"]))),
@@ -125,8 +132,9 @@ def test_sweep_every_pair_against_oracle(wset, C, POOL):
     assert not failures, failures
     # the default arithmetic has the error of an fp32 evaluation: within 2x of the all-fp32 mode (+ 2e-6 of fp32 noise floor)
     m = report["modes"]
-    assert m["default"]["abs_d_overlap"]["max"] <= 2 * m["all_f32"]["abs_d_overlap"]["max"] + 2e-6, \
-        (m["default"]["abs_d_overlap"], m["all_f32"]["abs_d_overlap"])
+    for name in ("default", "default_cached"):
+        assert m[name]["abs_d_overlap"]["max"] <= 2 * m["all_f32"]["abs_d_overlap"]["max"] + 2e-6, \
+            (name, m[name]["abs_d_overlap"], m["all_f32"]["abs_d_overlap"])
 
 
 # ---- the full stack: raw clouds -> projection + normals -> leg -> heads (BASELINE configs[4] as bench.py's `fullstack` step runs it) ----
