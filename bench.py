@@ -585,6 +585,20 @@ def main():
         step = make_step_cold(raw)
     else:
         step = step_warm
+    # dead-channel compaction (ovn_set_head_compaction): the contraction walks ceil(live / 32) of the 4 channel slices, where `live`
+    # counts the channels that are non-zero somewhere in the QUERY's 360 columns -- measured here on the queries of the timed stream
+    # (BEFORE the timed region -- the launches after it stay full-size sweeps, which the traffic passes read --
+    #  read back from the library after an untimed sweep per query: ovn_head_walk_stats -- slices walked by each of the 12 passes)
+    live_counts, walks = [], []
+    if args.mode == "warm" and args.head_precision == "f16x3" and spectral and P > 0:
+        n_w = min(P, 32)
+        for qi in query_ring:
+            fq = eng.leg(qi)
+            eng.heads(cands[:n_w], fq, spec_l=cand_spec[:n_w], spec_r=eng.spectrum(fq), dcache_l=cand_dc[:n_w] if cand_dc is not None else None)
+            st = eng.head_walk_stats()
+            live_counts.append(st["live_channels"])
+            walks.append(st["k_walk_frac"])
+    walk_frac = (sum(walks) / len(walks)) if walks else 1.0
     elapsed, prof, res = timed(step, args.warmup, args.steps, eng, use_dist, dev, side_eng=qa.side if qa is not None else None)
     if args.mode == "warm":
         # query 0 in a step of its own (untimed): what the accuracy block below and the same-results checks compare.  Serial order:
@@ -639,19 +653,6 @@ def main():
         launch_pairs = P * args.steps / d_n
     kname, peak, kprefix, flop_per_pair, rl_note = HEAD_KERNEL[args.head_precision]
     achieved = flop_per_pair * launch_pairs / (avg_ms * 1e-3) / 1e12 if d_n else 0.0
-    # dead-channel compaction (ovn_set_head_compaction): the contraction walks ceil(live / 32) of the 4 channel slices, where `live`
-    # counts the channels that are non-zero somewhere in the QUERY's 360 columns -- measured here on the queries of the timed stream
-    # (read back from the library after an untimed sweep per query: ovn_head_walk_stats -- slices walked by each of the 12 passes)
-    live_counts, walks = [], []
-    if args.mode == "warm" and args.head_precision == "f16x3" and spectral and P > 0:
-        n_w = min(P, 32)
-        for qi in query_ring:
-            fq = eng.leg(qi)
-            eng.heads(cands[:n_w], fq, spec_l=cand_spec[:n_w], spec_r=eng.spectrum(fq), dcache_l=cand_dc[:n_w] if cand_dc is not None else None)
-            st = eng.head_walk_stats()
-            live_counts.append(st["live_channels"])
-            walks.append(st["k_walk_frac"])
-    walk_frac = (sum(walks) / len(walks)) if walks else 1.0
     mfma_per_alg = (3.0 * walk_frac) if args.head_precision == "f16x3" else 1.0
     if strong:
         workload = ("1-vs-%d synthetic candidate pool sharded over %d rank(s) in contiguous blocks (BASELINE configs[3]; warm: 1 query "

@@ -40,6 +40,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "ovn_internal.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 // JBP (column groups per pass): 2 for sweeps; 1 for a handful of pairs (24 half-passes per pair = 24 workgroups: twice the
 // parallelism for the single-pair latency of demo2 / gated demo3 queries; same per-accumulator order, same bits).
 template <int SPC, int ABL = 0, int JBP = 2>
-__global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __restrict__ desc,
+__global__ __launch_bounds__(512) void delta_c1_r5_kernel(const DeltaDesc* __restrict__ desc,
                                                              const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
                                                              float* __restrict__ o1raw, int rot, int nsplit, int pair0,
                                                              const int32_t* __restrict__ lidx, const unsigned* __restrict__ live,
@@ -1113,6 +1115,256 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 #undef OVN_DMA_R
 }
 
+// ---- round 6: the contraction with TRANSPOSED passes ---------------------------------------------------------------------------
+// A pair is 360 x 24 (row i, column group jb) combinations = 540 MFMA row tiles exactly, but 360 rows are 22.5 tiles: the kernel above
+// (rounds 2-5: wave = 48 rows x two column groups per pass) pads every column group to 24 tiles -- 6.7 % of its MFMAs, in the busiest
+// SIMD of every pass.  Here a pass is RT = 2 row tiles (32 rows) x ALL 24 column groups: wave w holds column groups 3 w .. 3 w + 2 of
+// both row tiles (the same 96 accumulators), eleven such passes cover rows 0 .. 351 without a padded slot, and ONE short pass takes
+// the last 8 rows of all 24 column groups as 12 tiles of (8 rows x 2 column groups) -- 3 per SIMD: 11.25 pass-times instead of 12.
+// What moves with it:
+//   * L (the candidate's words, pair-specific, from HBM): a pass needs 32 rows of every walked channel -- 4 KB per slice, SHARED by the
+//     eight waves, fetched ONCE per pair (184 KB) instead of once per pass (12 x 184 KB);
+//   * R (the query's words, shared by every pair of the sweep: L2-resident): all 24 column groups, streamed chunk by chunk beside the
+//     W1 window (9 KB per chunk of 3 steps) instead of two column groups resident per pass;
+//   * the slice counts of the dead-channel compaction become per WAVE SLOT: a pass walks the largest count of the query, a column
+//     group whose own live channels end earlier skips the MFMAs of the slices beyond (wave-uniform).
+// Same per-accumulator order as before (slices cyclically from the slot's rotation, taps 0 .. 14, hi hi / lo hi / hi lo), same o1raw
+// layout, same c_conv2 kernel.  RT = 1 (16 rows x 24 column groups, 22 + 1 passes = 23 workgroups per pair) serves a handful of pairs.
+constexpr int T_LBLK = 8 * 32 + 16;                       // words of one L block: [8 positions][32 rows] + 16 of padding (bank spread)
+constexpr int T_LSL_WORDS = 4 * T_LBLK;                   // one L slice (32 positions x 32 rows): 4,352 B
+constexpr int T_TAIL_ROW0 = (FW / 16) * 16;               // 352: first row of the short pass
+static_assert(FW - T_TAIL_ROW0 == 8 && G % 3 == 0 && G / 3 == NWAVE, "pass geometry");
+// SPC = MFMA steps (taps) per chunk: W1 fragments SPC x 8 KB + R words [jb(24)][tap(SPC)][g(4)][8] = SPC x 3 KB per chunk
+constexpr size_t t_lds_bytes(int spc) { return 2 * (size_t)spc * STEP_BYTES + 2 * (size_t)G * spc * 32 * 4 + 2 * (size_t)T_LSL_WORDS * 4; }
+
+template <int RT, int T_SPC>
+__global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __restrict__ desc, const _Float16* __restrict__ w1p,
+                                                             const f32x4* __restrict__ scales, float* __restrict__ o1raw, int rot,
+                                                             int nsplit, int pair0, const int32_t* __restrict__ lidx,
+                                                             const unsigned* __restrict__ live, const _Float16* __restrict__ w1c) {
+  constexpr int NFULL = (FW / 16) / RT;          // full passes: 11 (RT 2) / 22 (RT 1)
+  constexpr int NPASS = NFULL + 1;               // + the short pass over rows 352 .. 359
+  constexpr int T_CHB = T_SPC * STEP_BYTES;      // W1 fragments of a chunk
+  constexpr int T_CPS = S / T_SPC;               // chunks per channel slice
+  constexpr int T_RCH_WORDS = G * T_SPC * 32;    // R words of a chunk
+  constexpr int PFN = T_CHB / (512 * 16);        // W1 DMA instructions per lane and chunk
+  constexpr int RPJ = T_SPC * 8;                 // 16-byte pieces of an R chunk per column group
+  constexpr int RFN = (G * RPJ + 511) / 512;     // R DMA instructions per lane and chunk (the last one partial, whole waves)
+  static_assert(S % T_SPC == 0 && T_CHB % (512 * 16) == 0 && T_CPS >= 2 && (G * RPJ) % 64 == 0, "bad chunking");
+  __shared__ __attribute__((aligned(16))) unsigned char chan_s[CHAN_BYTES];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned char* wst = smem_raw;                                                   // [2][T_CHB]
+  unsigned* rbuf = reinterpret_cast<unsigned*>(smem_raw + 2 * T_CHB);              // [2][T_RCH_WORDS]
+  unsigned* lbuf = rbuf + 2 * T_RCH_WORDS;                                         // [2][T_LSL_WORDS]
+
+  const int pair = blockIdx.x / nsplit;
+  const int part = blockIdx.x - pair * nsplit;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane & 15;
+  const int g = lane >> 4;
+
+  const unsigned* L = desc[pair].pl;     // channel-major [c][360]: per-pair scratch or the candidate's cache row
+  const unsigned* Rw = desc[pair].pr;    // [jb][slice][tap][g][8]: per-pair scratch or the query's shared words
+  const float krow = scales[2 * pair][1];
+  const bool compact = live != nullptr && scales[2 * pair + 1][3] != 0.0f;   // workgroup-uniform
+  (void)load_chan_table(live, compact, chan_s, tid);
+  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(compact ? w1c : w1p);
+  __syncthreads();   // channel table
+
+  // slices walked: by the workgroup (the largest count of any column-group pair) and by this wave's slots
+  int nsm = 1;
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) nsm = max(nsm, (int)chan_s[FC + p]);
+  nsm = __builtin_amdgcn_readfirstlane(nsm);
+  int ns_full[3], ns_tail[2];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) ns_full[j] = __builtin_amdgcn_readfirstlane((int)chan_s[FC + ((3 * wave + j) >> 1)]);
+  // short pass: waves 0 .. 3 take two tiles (column groups 4 w .. 4 w + 3), waves 4 .. 7 one (16 + 2 (w - 4), + 1): three per SIMD
+  const int tail_jb0 = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 * wave : 16 + 2 * (wave - 4));
+  const int tail_slots = wave < 4 ? 2 : 1;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) ns_tail[j] = __builtin_amdgcn_readfirstlane((int)chan_s[FC + ((tail_jb0 + 2 * j) >> 1)]);
+
+  // rotation of the K walk by the CANDIDATE's slot in the left pool (see the header of ovn_heads): a pair's bits depend neither on the
+  // chunking of the sweep nor on the order of an index list, and a 32-aligned shard reproduces the unsharded sweep
+  const int slot = lidx ? lidx[pair] : pair0 + pair;
+  const int s0 = (rot ? ((slot >> 3) & 3) : 0) % nsm;
+  const int p_begin = part * NPASS / nsplit, p_end = (part + 1) * NPASS / nsplit;
+
+#define OVN_DMA_W(CH, BUF)                                                                        \
+  _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                 \
+      glds16(w1bytes + (size_t)(CH) * T_CHB + (q * 512 + tid) * 16, wst + (BUF) * T_CHB + (q * 512 + wave * 64) * 16);
+  // piece idx = q 512 + tid of an R chunk: column group idx / RPJ, 16 bytes idx % RPJ of its T_SPC taps (contiguous in the packed volume)
+#define OVN_DMA_R(SL, C5, BUF)                                                                    \
+  _Pragma("unroll") for (int q = 0; q < RFN; ++q) {                                               \
+    const int idx = q * 512 + tid;                                                                \
+    const int jb_ = idx / RPJ, pc_ = idx - RPJ * jb_;                                             \
+    if (q * 512 + wave * 64 < G * RPJ)                                                            \
+      glds16(Rw + jb_ * K1 + ((SL) * S + T_SPC * (C5)) * 32 + pc_ * 4, rbuf + (BUF) * T_RCH_WORDS + (q * 512 + wave * 64) * 4); \
+  }
+  // L slice SL of the pass that starts at row ROW0 and holds ROWS rows: block q (wave q < 4) = positions 8 q .. 8 q + 7, a lane moves
+  // rows 4 (lane & 7) .. + 3 of position 8 q + (lane >> 3): 16 contiguous bytes of the channel-major volume, nothing past row 359
+#define OVN_DMA_L(SL, ROW0, ROWS, BUF)                                                            \
+  if (wave < 4 && 4 * (lane & 7) < (ROWS))                                                        \
+    glds16(L + (size_t)chan_s[(SL) * 32 + 8 * wave + (lane >> 3)] * FW + (ROW0) + 4 * (lane & 7),  \
+           lbuf + (BUF) * T_LSL_WORDS + wave * T_LBLK);
+
+  int cur = 0, lcur = 0;
+  {
+    const bool tail0 = p_begin == NFULL;
+    OVN_DMA_W(T_CPS * s0, 0)
+    OVN_DMA_R(s0, 0, 0)
+    OVN_DMA_L(s0, tail0 ? T_TAIL_ROW0 : 16 * RT * p_begin, tail0 ? 8 : 16 * RT, 0)
+  }
+  __syncthreads();
+
+  // One pass.  TAIL = false: NT = RT row tiles x NJ = 3 column groups per wave; TAIL = true: one tile row (8 rows, both halves of the
+  // 16 lanes-rows: column groups jb, jb + 1) x NJ = 2 slots.
+  auto run_pass = [&](auto tail_tag, int pass) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    constexpr int NT = TAIL ? 1 : RT;
+    constexpr int NJ = TAIL ? 2 : 3;
+    const bool has_next = pass + 1 < p_end;
+    const bool next_tail = pass + 1 == NFULL;
+    const int row0_n = next_tail ? T_TAIL_ROW0 : 16 * RT * (pass + 1);
+    const int rows_n = next_tail ? 8 : 16 * RT;
+    const int row0 = TAIL ? T_TAIL_ROW0 : 16 * RT * pass;
+    f32x4 acc[NJ][NT][4];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // word offset of this lane's R words inside a chunk, per slot: column group x 96 + 8 g (TAIL: the lane's half picks the group)
+    int rofs[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rofs[j] = (TAIL ? tail_jb0 + 2 * j + (lrow >> 3) : 3 * wave + j) * (T_SPC * 32) + 8 * g;
+    u32x4 la[NT][2];
+#pragma unroll 1
+    for (int q4 = 0; q4 < nsm; ++q4) {
+      const int sl = (s0 + q4 >= nsm) ? s0 + q4 - nsm : s0 + q4;
+      const bool last_slice = q4 + 1 == nsm;
+      const int sl_n = last_slice ? s0 : ((sl + 1 == nsm) ? 0 : sl + 1);
+      {
+        const unsigned* lw = lbuf + lcur * T_LSL_WORDS + g * T_LBLK + (TAIL ? (lrow & 7) : lrow);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            la[t][0][e] = lw[e * 32 + 16 * t];
+            la[t][1][e] = lw[(4 + e) * 32 + 16 * t];
+          }
+      }
+      bool act[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) act[j] = TAIL ? (j < tail_slots && sl < ns_tail[j]) : (sl < ns_full[j]);
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) any = any || act[j];
+      // A slice beyond a column group's own walk adds exact zeros to it (its channels there are dead in the query's columns of that
+      // group), so skipping is only ever an optimisation: a wave skips the MFMAs of a slice when NONE of its slots walks it -- one
+      // wave-uniform test per chunk; a test per slot would end the scheduling region at every slot
+#pragma unroll 1
+      for (int c5 = 0; c5 < T_CPS; ++c5) {
+        {   // the next chunk of the walk (the first one of the next pass after the last): W1 fragments + R words, one chunk ahead
+          const int sl_x = (c5 + 1 < T_CPS) ? sl : sl_n, c5_x = (c5 + 1 < T_CPS) ? c5 + 1 : 0;
+          OVN_DMA_W(T_CPS * sl_x + c5_x, cur ^ 1)
+          OVN_DMA_R(sl_x, c5_x, cur ^ 1)
+        }
+        if (c5 == 1) {   // the next L slice: of this pass, or the first of the next pass
+          if (!last_slice) {
+            OVN_DMA_L(sl_n, row0, TAIL ? 8 : 16 * RT, lcur ^ 1)
+          } else if (has_next) {
+            OVN_DMA_L(sl_n, row0_n, rows_n, lcur ^ 1)
+          }
+        }
+        if (any) {
+          const unsigned char* wcur = wst + cur * T_CHB;
+          const unsigned* rcur = rbuf + cur * T_RCH_WORDS;
+          u32x4 rw[NJ][2];
+          f16x8 bh[2][4], bl[2][4];
+          f16x8 ah[2], al[2];
+#define OVN_READ_B(SET, H)                                                                          \
+  _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                \
+    bh[SET][nt] = *reinterpret_cast<const f16x8*>(wcur + (H) * STEP_BYTES + ((nt * 2 + 0) * 64 + lane) * 16); \
+    bl[SET][nt] = *reinterpret_cast<const f16x8*>(wcur + (H) * STEP_BYTES + ((nt * 2 + 1) * 64 + lane) * 16); \
+  }
+#define OVN_READ_R(J, H)                                                                            \
+  {                                                                                                 \
+    rw[J][0] = *reinterpret_cast<const u32x4*>(rcur + rofs[J] + (H) * 32);                           \
+    rw[J][1] = *reinterpret_cast<const u32x4*>(rcur + rofs[J] + (H) * 32 + 4);                       \
+  }
+          // The chunk as a chain of slot regions (q = step x slot, slot = (row tile, column group)), fenced from each other: region q
+          // forms the operands of slot q + 1 (16 VALU) next to the 12 MFMAs of slot q, requests a column group's R words of the next
+          // step once its last tile of this step has taken them, and the next step's W1 fragments at the first slot of a step.
+          // Unfenced, the scheduler hoists every operand formation and fragment read of a step to its top: 344 spilled registers.
+          constexpr int NS = NT * NJ;
+          OVN_READ_B(0, 0)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) OVN_READ_R(j, 0)
+          make_a(la[0][0], la[0][1], rw[0][0], rw[0][1], ah[0], al[0]);
+#pragma unroll
+          for (int q = 0; q < T_SPC * NS; ++q) {
+            const int h = q / NS, k = q - NS * h, t = k / NJ, j = k - NJ * t;
+            __builtin_amdgcn_sched_barrier(0);
+            if (k == 0 && h + 1 < T_SPC) OVN_READ_B((h + 1) & 1, h + 1)
+            if (t == NT - 1 && h + 1 < T_SPC) OVN_READ_R(j, h + 1)
+            if (q + 1 < T_SPC * NS) {
+              const int k1 = (q + 1) % NS, t1 = k1 / NJ, j1 = k1 - NJ * t1;
+              make_a(la[t1][0], la[t1][1], rw[j1][0], rw[j1][1], ah[(q + 1) & 1], al[(q + 1) & 1]);
+            }
+            {
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1], bh[h & 1][nt], acc[j][t][nt], 0, 0, 0);
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[q & 1], bh[h & 1][nt], acc[j][t][nt], 0, 0, 0);
+#pragma unroll
+              for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[q & 1], bl[h & 1][nt], acc[j][t][nt], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#undef OVN_READ_B
+#undef OVN_READ_R
+        }
+        __syncthreads();   // vmcnt(0): the DMAs issued above have landed; every wave is done with buffers `cur`
+        cur ^= 1;
+      }
+      lcur ^= 1;
+    }
+    // -2 M s1r -> o1raw in the streaming order of delta_c2_f16x3_kernel: [tile of 192 rows = (pair, jb / 8)][k-step 2 di + (o' >> 5)]
+    // [row = (jb % 8) 24 + ib][o' & 31], o' = 4 lrow + nt: 16 bytes per lane.  The stores drain behind the next pass's first chunk.
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if (TAIL && j >= tail_slots) continue;
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lr = 4 * g + r;
+          const int jb = TAIL ? tail_jb0 + 2 * j + (lr >> 3) : 3 * wave + j;
+          const int i = TAIL ? T_TAIL_ROW0 + (lr & 7) : row0 + 16 * t + lr;
+          const int ib = i / S, di = i - ib * S;
+          float* dst = o1raw + ((size_t)pair * 3 + (jb >> 3)) * (C2_TILE_ROWS * K2) + (size_t)(2 * di + (lrow >> 3)) * (C2_TILE_ROWS * 32) +
+                       ((jb & 7) * G + ib) * 32 + 4 * (lrow & 7);
+          const f32x4 v = {acc[j][t][0][r] * krow, acc[j][t][1][r] * krow, acc[j][t][2][r] * krow, acc[j][t][3][r] * krow};
+          // streaming stores: the 2.2 MB per pair pass through L2 without displacing the W1 / R lines
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(dst));
+        }
+    }
+  };
+
+  for (int pass = p_begin; pass < p_end; ++pass) {
+    if (pass < NFULL) run_pass(std::false_type{}, pass);
+    else run_pass(std::true_type{}, pass);
+  }
+#undef OVN_DMA_L
+#undef OVN_DMA_W
+#undef OVN_DMA_R
+}
+
 // c_conv2 on the stored -2 M rows: a (n 576) x 960 x 128 GEMM, HBM-bound (3840 B read per row, 0.2 ms of MFMA per 1024 pairs).
 // Workgroup = 64 MT consecutive rows (row = (pair 24 + jb) 24 + ib; a tile may straddle two pairs), 4 waves x 16 MT rows x all 128
 // columns.  The kernel is bound by load latency x bytes in flight: the A rows are read straight into registers TWO k-steps ahead
@@ -1267,17 +1519,16 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
 }
 
 static int pick_nsplit(int n) {
-  // divisors of the 12 passes: time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's work; the smallest d within
-  // 5 % of the best (big sweeps keep d = 1: one workgroup per pair).  d = 24 (half-passes: one column group per workgroup) only
-  // for <= 10 pairs, where the 240 workgroups still fit ONE round: a half-pass workgroup walks the whole K / W1 stream like a full
-  // pass does, so it does not cost half a pass and loses as soon as it adds a round (n = 32: 768 workgroups in 3 rounds against
-  // 384 in 2 -- ADVICE r4)
+  // divisors of the 12 passes (11 of two row tiles + the short one): time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's
+  // work; the smallest d within 5 % of the best (big sweeps keep d = 1: one workgroup per pair).  d = 23 (ONE row tile per pass, 22 + 1
+  // passes, one per workgroup) only for <= 10 pairs, where the 230 workgroups still fit ONE round: such a workgroup walks the whole
+  // K / W1 stream like a two-tile pass does, so it does not cost half of one and loses as soon as it adds a round
   double best = 1e30;
   auto cost = [n](int d) { return (double)(((long long)n * d + 255) / 256) / d; };
-  auto allowed = [n](int d) { return d < 24 || n <= 10; };
-  for (const int d : {1, 2, 3, 4, 6, 12, 24})
+  auto allowed = [n](int d) { return d < 23 || n <= 10; };
+  for (const int d : {1, 2, 3, 4, 6, 12, 23})
     if (allowed(d) && cost(d) < best) best = cost(d);
-  for (const int d : {1, 2, 3, 4, 6, 12, 24})
+  for (const int d : {1, 2, 3, 4, 6, 12, 23})
     if (allowed(d) && cost(d) <= 1.05 * best) return d;
   return 1;
 }
@@ -1317,7 +1568,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   const unsigned* live = (ridx || !ctx->head_compact) ? nullptr : live_buf;
   ctx->dbg_live = live;   // ovn_head_walk_stats: the K walk of the most recent sweep (its last chunk)
   *o2max_out = o2max;
-  const int nsplit = pick_nsplit(n);   // 24: half-passes (one column group per workgroup), chosen for <= 10 pairs
+  const int nsplit = pick_nsplit(n);   // 23: one row tile per pass and one pass per workgroup, chosen for <= 10 pairs
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
@@ -1335,41 +1586,40 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-#define OVN_C1_LAUNCH(SPCV, ...)                                                                                             \
-  {                                                                                                                          \
-    constexpr size_t lds = 2 * (size_t)(SPCV) * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;                          \
-    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), lds);              \
-    if (rc) return rc;                                                                                                       \
-    hipLaunchKernelGGL((delta_c1_f16x3_kernel<SPCV, ##__VA_ARGS__>), dim3(n * nsplit), dim3(512), lds, stream, desc,         \
-                       reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);     \
-  }
-    if (nsplit == 24) {
+    static const bool use_r5 = getenv("OVN_C1_R5") != nullptr;   // A/B against the round-5 kernel (development only)
+    if (use_r5) {
+      const int ns5 = nsplit == 23 ? 24 : nsplit;
       constexpr size_t lds = 2 * (size_t)3 * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;
-      rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<3, 0, 1>), lds);
+      if (ns5 == 24) {
+        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_r5_kernel<3, 0, 1>), lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((delta_c1_r5_kernel<3, 0, 1>), dim3(n * ns5), dim3(512), lds, stream, desc,
+                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, ns5, pair0, lidx, live, w1c);
+      } else {
+        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_r5_kernel<3>), lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL((delta_c1_r5_kernel<3>), dim3(n * ns5), dim3(512), lds, stream, desc,
+                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, ns5, pair0, lidx, live, w1c);
+      }
+    } else if (nsplit == 23) {   // a handful of pairs: one row tile per pass, one pass per workgroup
+      rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<1, 3>), t_lds_bytes(3));
       if (rc) return rc;
-      hipLaunchKernelGGL((delta_c1_f16x3_kernel<3, 0, 1>), dim3(n * nsplit), dim3(512), lds, stream, desc,
+      hipLaunchKernelGGL((delta_c1_f16x3_kernel<1, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,
                          reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
-    } else
-#ifdef OVN_ABLATE
-    switch (getenv("OVN_C1_VARIANT") ? atoi(getenv("OVN_C1_VARIANT")) : 0) {   // tools/experiments/c1_variants.py
-      case 2: OVN_C1_LAUNCH(5) break;
-      case 101: OVN_C1_LAUNCH(3, 1) break;
-      case 102: OVN_C1_LAUNCH(3, 2) break;
-      case 104: OVN_C1_LAUNCH(3, 4) break;
-      case 108: OVN_C1_LAUNCH(3, 8) break;
-      case 116: OVN_C1_LAUNCH(3, 16) break;
-      case 127: OVN_C1_LAUNCH(3, 27) break;
-      case 131: OVN_C1_LAUNCH(3, 31) break;
-      case 164: OVN_C1_LAUNCH(3, 64) break;
-      case 228: OVN_C1_LAUNCH(3, 128) break;
-      case 292: OVN_C1_LAUNCH(3, 192) break;
-      case 356: OVN_C1_LAUNCH(3, 256) break;
-      default: OVN_C1_LAUNCH(3) break;
+    } else {
+      static const int spc = getenv("OVN_C1_SPC") ? atoi(getenv("OVN_C1_SPC")) : 3;
+      if (spc == 5) {
+        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<2, 5>), t_lds_bytes(5));
+        if (rc) return rc;
+        hipLaunchKernelGGL((delta_c1_f16x3_kernel<2, 5>), dim3(n * nsplit), dim3(512), t_lds_bytes(5), stream, desc,
+                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
+      } else {
+        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<2, 3>), t_lds_bytes(3));
+        if (rc) return rc;
+        hipLaunchKernelGGL((delta_c1_f16x3_kernel<2, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,
+                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
+      }
     }
-#else
-    OVN_C1_LAUNCH(3)
-#endif
-#undef OVN_C1_LAUNCH
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_C2, stream);
