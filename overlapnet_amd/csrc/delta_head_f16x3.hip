@@ -27,8 +27,8 @@
 // Three kernels per call (plus delta_a2_kernel for the right volumes):
 //   delta_prepare_split_kernel  per pair: value range -> shift and scales, both volumes packed into the word streams below, TT, AA
 //   delta_c1_f16x3_kernel       the min-term contraction; NO epilogue phase: it stores -2 M (scaled, fp32) and goes on with the
-//                               next column groups; registers hold the 96 accumulators, one L slice and the operand fragments, and
-//                               every operand stream (W1 window, packed R rows, packed L slices) arrives by LDS-DMA
+//                               next rows; registers hold the 96 accumulators, the pass's L words and the operand fragments, and
+//                               every operand stream (W1 window, packed R words, packed L slices) arrives by LDS-DMA
 //                               (global_load_lds_dwordx4): no staging registers, no ds_write pass, no exposed global-load latency
 //   delta_c2_f16x3_kernel       c_conv2 as a streaming GEMM over the (n 576) x 960 matrix of -2 M rows (2.2 MB per pair through HBM)
 // The one-kernel predecessor (o1 image in LDS, c_conv2 as an epilogue phase of every pass: 5.56 ms per 1024 pairs against
@@ -59,7 +59,6 @@ constexpr int O2 = OVN_C2_OUT;        // 128
 constexpr int K1 = S * FC;            // 1920
 constexpr int K2 = S * O1;            // 960
 constexpr int STEP_BYTES = 8192;      // W1 fragments of one MFMA step: [nt(4)][hi/lo][lane(64)][8 fp16]
-constexpr size_t RS_BYTES = 2 * (size_t)S * FC * 4;   // packed R rows of two column groups (one pass): 15,360 B
 constexpr int NWAVE = 8;
 constexpr int A2_ELEMS = G * O1;                   // floats of A2 per right volume [jb][o]
 constexpr int A2_KSPLIT = 8;                       // K slices (workgroups) per right volume in delta_a2_kernel
@@ -260,8 +259,6 @@ __global__ void delta_prep_ws_f16_kernel(const float* __restrict__ w1sum, _Float
   }
 }
 
-constexpr int R_PASS_WORDS = 2 * S * FC;            // packed R rows of one pass (two column groups): 3840 words = 15,360 B
-constexpr int LST_WAVE_BYTES = 6 * 1024;            // one wave's L slice: 3 row tiles x 2 x 16 B per lane
 constexpr int TT_STRIDE = K2 + 8;                   // fp16 elements per row of the T image in LDS (1936 B: 16-B reads of 16 rows spread over all banks)
 constexpr int LIN_ELEMS = 2 * G * O2;               // per pair: TT + b2 [24][128], AA [24][128]
 constexpr size_t O1RAW_ELEMS = (size_t)G * FW * O1; // per pair: 552,960 floats = 3 tiles of 192 (jb, ib) rows x 960
@@ -911,225 +908,27 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
   }
 }
 
-// c_conv1's min-term contraction.  One workgroup of 8 waves = one pair (or 1/nsplit of its 12 passes); wave w owns rows
-// 48w .. 48w+47 of TWO column groups per pass (96 accumulator registers), K walked channel-slice-major as in the fused kernel.
-// LDS: W1 window 2 x SPC x 8 KB | packed R rows of the current and the next pass 2 x 15,360 B | one L slice per wave 8 x 6 KB.
-// All three are filled by LDS-DMA issued one chunk (W1), one slice (L) or one pass (R) ahead; the chunk barrier's vmcnt(0) finds them
-// landed (a chunk is SPC x 72 MFMAs per wave = 3.3 us at SPC = 3).  Output: o1raw = -2 M s1r in the streaming order of the c_conv2 kernel
-// (tile of 192 (jb, ib) rows, k-step major; K order of W2p: o' = 4 (o & 15) + (o >> 4)), 16 bytes per lane and accumulator row.
-// ABL (timing-only, -DOVN_ABLATE builds): 1 no o1 stores, 2 no W1 DMA, 4 no chunk barrier, 8 no L DMA / slice reads, 16 no R DMA,
-// 64 W1 DMA always from chunk 0 (cache-resident source), 128 o1 stores of every pair into 256 pairs' rows (cache-resident destination)
-// JBP (column groups per pass): 2 for sweeps; 1 for a handful of pairs (24 half-passes per pair = 24 workgroups: twice the
-// parallelism for the single-pair latency of demo2 / gated demo3 queries; same per-accumulator order, same bits).
-template <int SPC, int ABL = 0, int JBP = 2>
-__global__ __launch_bounds__(512) void delta_c1_r5_kernel(const DeltaDesc* __restrict__ desc,
-                                                             const _Float16* __restrict__ w1p, const f32x4* __restrict__ scales,
-                                                             float* __restrict__ o1raw, int rot, int nsplit, int pair0,
-                                                             const int32_t* __restrict__ lidx, const unsigned* __restrict__ live,
-                                                             const _Float16* __restrict__ w1c) {
-  constexpr int CHB = SPC * STEP_BYTES;          // window chunk
-  constexpr int CPS = S / SPC;                   // chunks per channel slice
-  __shared__ __attribute__((aligned(16))) unsigned char chan_s[CHAN_BYTES];   // channel of position 32 sc + 8 g + e of this pair's K walk | slices per column-group pair
-  constexpr int PFN = CHB / (512 * 16);          // DMA instructions per lane per chunk
-  static_assert(S % SPC == 0 && CHB % (512 * 16) == 0 && CPS >= 3, "bad chunking");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  unsigned char* wst = smem_raw;
-  unsigned* rbuf = reinterpret_cast<unsigned*>(smem_raw + 2 * CHB);
-  unsigned char* lst = smem_raw + 2 * CHB + 2 * RS_BYTES;
-
-  const int pair = blockIdx.x / nsplit;
-  const int part = blockIdx.x - pair * nsplit;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int lrow = lane & 15;
-  const int g = lane >> 4;
-
-  const unsigned* L = desc[pair].pl;     // per-pair scratch, or the candidate's cache row / the query's shared words
-  const unsigned* Rw = desc[pair].pr;
-  const float krow = scales[2 * pair][1];
-  // the K walk of this pair: the query's compacted channel list (ns slices of 32 live channels, W1 fragments gathered for them) when
-  // the pair has no shift, the plain one (4 slices, the resident W1 fragments) otherwise -- workgroup-uniform
-  const bool compact = live != nullptr && scales[2 * pair + 1][3] != 0.0f;
-  (void)load_chan_table(live, compact, chan_s, tid);
-  const unsigned char* w1bytes = reinterpret_cast<const unsigned char*>(compact ? w1c : w1p);
-  unsigned char* lmine = lst + wave * LST_WAVE_BYTES;
-  __syncthreads();   // channel table
-
-  // The wave's L slice in LDS: [channel position 0..31][row 0..47] words (6 KB).  DMA instruction q moves words 256 q + 4 lane .. + 3
-  // = rows r .. r + 3 of position cl: 16 contiguous bytes of the channel-major volume.  (Rows past the volume -- wave 7, r >= 24 --
-  // read into the next channel's rows: their accumulators are never stored.)
-  // (the six (position, row) pairs of a lane are recomputed at every slice -- a handful of integer instructions per 30 MFMA steps --
-  // instead of living in six registers of a kernel that has none to spare: the opaque copy keeps the compiler from hoisting them)
-#define OVN_DMA_L(SL)                                                                            \
-  {                                                                                              \
-    int lane_o = lane;                                                                           \
-    asm volatile("" : "+v"(lane_o));                                                             \
-    _Pragma("unroll") for (int q = 0; q < 6; ++q) {                                              \
-      const int o = (q * 64 + lane_o) * 4;                                                       \
-      const int cl = o / 48, r = o - 48 * cl;                                                    \
-      glds16(L + (size_t)chan_s[(SL) * 32 + cl] * FW + 48 * wave + r, lmine + q * 1024);         \
-    }                                                                                            \
-  }
-#define OVN_DMA_W(CH, BUF)                                                                       \
-  _Pragma("unroll") for (int q = 0; q < PFN; ++q)                                                \
-      glds16(w1bytes + (size_t)(CH) * CHB + (q * 512 + tid) * 16, wst + (BUF) * CHB + (q * 512 + wave * 64) * 16);
-#define OVN_DMA_R(PASS, BUF)                                                                     \
-  {                                                                                              \
-    const unsigned* rsrc = Rw + (size_t)(PASS) * (JBP * S * FC);                                  \
-    if (JBP == 2 || tid * 4 < S * FC)   /* JBP 1: exactly the group's S * FC words -- nothing past this pair's packed R block is read */ \
-      glds16(rsrc + tid * 4, rbuf + (BUF) * R_PASS_WORDS + wave * 256);                           \
-    if (JBP == 2 && wave < 7) glds16(rsrc + (512 + tid) * 4, rbuf + (BUF) * R_PASS_WORDS + (512 + wave * 64) * 4); \
-  }
-
-  // rotation of the K walk by the CANDIDATE's slot in the left pool (its index-list entry, or its position in the pool when the
-  // sweep has no list; pair0 = slot of this launch's first pair): the summation order of a pair, and with it the last bits of its
-  // result, depends neither on how the sweep is cut into launches nor on where the candidate stands in an index list -- a shard
-  // of a pool whose first slot is a multiple of 32 (overlapnet_amd.distributed) reproduces the bits of the unsharded sweep
-  const int slot = lidx ? lidx[pair] : pair0 + pair;
-  const int s0b = rot ? ((slot >> 3) & 3) : 0;
-  const int p_begin = part * (G / JBP) / nsplit, p_end = (part + 1) * (G / JBP) / nsplit;
-  // slices walked by a pass: those of its column-group pair (4 for a pair that is not compacted); the walk starts at slice s0b mod that
-#define OVN_NS_OF(PASS) ((int)__builtin_amdgcn_readfirstlane((int)chan_s[FC + ((JBP == 2) ? (PASS) : ((PASS) >> 1))]))
-  int ns = OVN_NS_OF(p_begin);
-  int s0 = s0b % ns;
-  int cur = 0, rcur = 0;
-  int chunk = CPS * s0;
-  OVN_DMA_W(chunk, 0)
-  OVN_DMA_R(p_begin, 0)
-  OVN_DMA_L(s0)
-  __syncthreads();
-
-  u32x4 la[3][2];   // this lane's words of the current L slice
-  for (int pass = p_begin; pass < p_end; ++pass) {
-    const int ns_n = (pass + 1 < p_end) ? OVN_NS_OF(pass + 1) : ns;   // the next pass's walk: where the prefetches at the end of this one go
-    const int s0_n = s0b % ns_n;
-    f32x4 acc[JBP][3][4];
-#pragma unroll
-    for (int j = 0; j < JBP; ++j)
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc[j][t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const unsigned* rb = rbuf + rcur * R_PASS_WORDS + 8 * g;
-#pragma unroll 1
-    for (int q4 = 0; q4 < ns; ++q4) {
-      const int sl = (s0 + q4 >= ns) ? s0 + q4 - ns : s0 + q4;
-      if (!(ABL & 8) || (pass == p_begin && q4 == 0)) {
-        // this lane's 8 words of each row tile: positions 8 g .. 8 g + 7 of the slice, row 16 t + lrow of the wave's 48
-        const unsigned* lw = reinterpret_cast<const unsigned*>(lmine) + (8 * g) * 48 + lrow;
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            la[t][0][e] = lw[e * 48 + 16 * t];
-            la[t][1][e] = lw[(4 + e) * 48 + 16 * t];
-          }
-      }
-      const unsigned* rsl = rb + sl * (S * 32);
-      const int sl_n = (q4 + 1 == ns) ? s0_n : ((sl + 1 == ns) ? 0 : sl + 1);   // the slice walked after this one
-#pragma unroll 1
-      for (int c5 = 0; c5 < CPS; ++c5) {
-        const int nxt = (c5 + 1 < CPS) ? chunk + 1 : CPS * sl_n;
-        if (!(ABL & 2)) OVN_DMA_W((ABL & 64) ? 0 : nxt, cur ^ 1)
-        if (!(ABL & 8) && c5 == 1) OVN_DMA_L(sl_n)                               // this wave read its la registers a barrier ago
-        if (!(ABL & 16) && c5 == 2 && q4 == 0 && pass + 1 < p_end) OVN_DMA_R(pass + 1, rcur ^ 1)
-        // operand fragments of step h+1 are read from LDS while step h's MFMAs run (two register sets, static indices)
-        u32x4 rw[2][4];
-        f16x8 bh[2][4], bl[2][4];
-#define OVN_READ_FRAGS(SET, H)                                                                     \
-  {                                                                                                \
-    const unsigned char* wbuf = wst + cur * CHB + (H) * STEP_BYTES;                                \
-    const unsigned* rrow = rsl + (c5 * SPC + (H)) * 32;                                            \
-    rw[SET][0] = *reinterpret_cast<const u32x4*>(rrow);                                            \
-    rw[SET][1] = *reinterpret_cast<const u32x4*>(rrow + 4);                                        \
-    if (JBP == 2) {                                                                                \
-      rw[SET][2] = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32);                             \
-      rw[SET][3] = *reinterpret_cast<const u32x4*>(rrow + 4 * S * 32 + 4);                         \
-    }                                                                                              \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                             \
-      bh[SET][nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 0) * 64 + lane) * 16);       \
-      bl[SET][nt] = *reinterpret_cast<const f16x8*>(wbuf + ((nt * 2 + 1) * 64 + lane) * 16);       \
-    }                                                                                              \
-  }
-        OVN_READ_FRAGS(0, 0)
-#pragma unroll
-        for (int h = 0; h < SPC; ++h) {
-          if (h + 1 < SPC) OVN_READ_FRAGS((h + 1) & 1, h + 1)
-#pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            f16x8 ah, al;
-            make_a(la[t][0], la[t][1], rw[h & 1][0], rw[h & 1][1], ah, al);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[h & 1][nt], acc[0][t][nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[h & 1][nt], acc[0][t][nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[0][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[h & 1][nt], acc[0][t][nt], 0, 0, 0);
-            if constexpr (JBP == 2) {
-              make_a(la[t][0], la[t][1], rw[h & 1][2], rw[h & 1][3], ah, al);
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) acc[JBP - 1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[h & 1][nt], acc[JBP - 1][t][nt], 0, 0, 0);
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) acc[JBP - 1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[h & 1][nt], acc[JBP - 1][t][nt], 0, 0, 0);
-#pragma unroll
-              for (int nt = 0; nt < 4; ++nt) acc[JBP - 1][t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[h & 1][nt], acc[JBP - 1][t][nt], 0, 0, 0);
-            }
-          }
-        }
-#undef OVN_READ_FRAGS
-        if (!(ABL & 4)) __syncthreads();   // vmcnt(0): the DMAs issued above have landed; every wave is done with window buffer `cur`
-        cur ^= 1;
-        chunk = nxt;
-      }
-    }
-    // -2 M s1r -> o1raw in the streaming order of delta_c2_f16x3_kernel: [tile of 192 rows = (pair, jb / 8)][k-step ks = 2 di + (o' >> 5)]
-    // [row = (jb % 8) 24 + ib][o' & 31], o' = 4 lrow + nt: 16 bytes per lane, 128-byte segments, 3 KB runs per (ks, jb).  The stores
-    // drain behind the next pass's first chunk.
-#pragma unroll
-    for (int j = 0; j < JBP; ++j) {
-      const int jb = JBP * pass + j;
-      float* obase = o1raw + ((size_t)((ABL & 128) ? (pair & 15) : pair) * 3 + (jb >> 3)) * (C2_TILE_ROWS * K2) +
-                     ((jb & 7) * G) * 32 + (lrow >> 3) * (C2_TILE_ROWS * 32) + 4 * (lrow & 7);
-#pragma unroll
-      for (int t = 0; t < 3; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int i = 48 * wave + 16 * t + 4 * g + r;
-          if ((ABL & 1) ? (acc[j][t][0][r] == 123.456f) : (i < FW)) {
-            const int ib = i / S, di = i - ib * S;
-            const f32x4 v = {acc[j][t][0][r] * krow, acc[j][t][1][r] * krow, acc[j][t][2][r] * krow, acc[j][t][3][r] * krow};
-            // streaming stores: the 2.2 MB per pair pass through L2 without displacing the W1 window's lines
-            if (ABL & 256) *reinterpret_cast<f32x4*>(obase + (size_t)(2 * di) * (C2_TILE_ROWS * 32) + ib * 32) = v;
-            else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(obase + (size_t)(2 * di) * (C2_TILE_ROWS * 32) + ib * 32));
-          }
-        }
-    }
-    rcur ^= 1;
-    ns = ns_n;
-    s0 = s0_n;
-  }
-#undef OVN_NS_OF
-#undef OVN_DMA_L
-#undef OVN_DMA_W
-#undef OVN_DMA_R
-}
-
-// ---- round 6: the contraction with TRANSPOSED passes ---------------------------------------------------------------------------
-// A pair is 360 x 24 (row i, column group jb) combinations = 540 MFMA row tiles exactly, but 360 rows are 22.5 tiles: the kernel above
-// (rounds 2-5: wave = 48 rows x two column groups per pass) pads every column group to 24 tiles -- 6.7 % of its MFMAs, in the busiest
-// SIMD of every pass.  Here a pass is RT = 2 row tiles (32 rows) x ALL 24 column groups: wave w holds column groups 3 w .. 3 w + 2 of
-// both row tiles (the same 96 accumulators), eleven such passes cover rows 0 .. 351 without a padded slot, and ONE short pass takes
-// the last 8 rows of all 24 column groups as 12 tiles of (8 rows x 2 column groups) -- 3 per SIMD: 11.25 pass-times instead of 12.
-// What moves with it:
+// c_conv1's min-term contraction, M[i][jb][o] = sum_{dj,c} min(l'[i][c], r'[15 jb + dj][c]) W1[dj][c][o].  One workgroup of 8 waves = one
+// pair (or 1/nsplit of its passes).  A pair is 360 x 24 (row i, column group jb) combinations = 540 MFMA row tiles exactly, but 360
+// rows are 22.5 tiles: the kernel of rounds 2-5 (wave = 48 rows x two column groups per pass, twelve passes; in the history up to
+// the round-5 tree) padded every column group to 24 tiles -- 6.7 % of its MFMAs, in the busiest SIMD of every pass.  Here a pass is
+// RT = 2 row tiles (32 rows) x ALL 24 column groups: wave w holds column groups 3 w .. 3 w + 2 of both row tiles (96 accumulator
+// registers), eleven such passes cover rows 0 .. 351 without a padded slot, and ONE short pass takes the last 8 rows of all 24
+// column groups as 12 tiles of (8 rows x 2 column groups), 3 per SIMD: 11.25 pass-times instead of 12 (SQ_INSTS_MFMA per 1024 pairs
+// at 3 slices: 3.185e8 -> 2.986e8; same-box A/B 3.05-3.09 -> 2.92 ms, profiles/r6_c1_transposed_ab.txt).  With it:
 //   * L (the candidate's words, pair-specific, from HBM): a pass needs 32 rows of every walked channel -- 4 KB per slice, SHARED by the
-//     eight waves, fetched ONCE per pair (184 KB) instead of once per pass (12 x 184 KB);
+//     eight waves, fetched ONCE per pair (184 KB) instead of once per pass (12 x 184 KB); nothing past row 359 is ever read;
 //   * R (the query's words, shared by every pair of the sweep: L2-resident): all 24 column groups, streamed chunk by chunk beside the
 //     W1 window (9 KB per chunk of 3 steps) instead of two column groups resident per pass;
-//   * the slice counts of the dead-channel compaction become per WAVE SLOT: a pass walks the largest count of the query, a column
-//     group whose own live channels end earlier skips the MFMAs of the slices beyond (wave-uniform).
-// Same per-accumulator order as before (slices cyclically from the slot's rotation, taps 0 .. 14, hi hi / lo hi / hi lo), same o1raw
-// layout, same c_conv2 kernel.  RT = 1 (16 rows x 24 column groups, 22 + 1 passes = 23 workgroups per pair) serves a handful of pairs.
+//   * the slice counts of the dead-channel compaction: a pass walks the LARGEST count of the query; a slice beyond a column group's own
+//     count adds exact zeros to it (its channels there are dead in that group's query columns), so a wave skips a slice's MFMAs when
+//     none of its slots walks it -- one wave-uniform test per chunk.
+// LDS (76 KB): W1 window 2 x 24 KB | R chunk 2 x 9 KB | L slice 2 x 4.25 KB, all filled by LDS-DMA one chunk / one slice ahead; the
+// chunk barrier's vmcnt(0) finds them landed.  Per-accumulator order as in rounds 2-5 (slices cyclically from the slot's rotation,
+// taps 0 .. 14, hi hi / lo hi / hi lo): the results have the bits of the round-5 kernel wherever every column group walks the same
+// slices.  Output: o1raw = -2 M s1r in the streaming order of the c_conv2 kernel (tile of 192 (jb, ib) rows, k-step major; K order of
+// W2p: o' = 4 (o & 15) + (o >> 4)), 16 bytes per lane and accumulator row.  RT = 1 (16 rows x 24 column groups, 22 + 1 passes = 23
+// workgroups per pair) serves a handful of pairs (the single-pair latency of demo2 / gated demo3 queries): same order, same bits.
 constexpr int T_LBLK = 8 * 32 + 16;                       // words of one L block: [8 positions][32 rows] + 16 of padding (bank spread)
 constexpr int T_LSL_WORDS = 4 * T_LBLK;                   // one L slice (32 positions x 32 rows): 4,352 B
 constexpr int T_TAIL_ROW0 = (FW / 16) * 16;               // 352: first row of the short pass
@@ -1586,39 +1385,16 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-    static const bool use_r5 = getenv("OVN_C1_R5") != nullptr;   // A/B against the round-5 kernel (development only)
-    if (use_r5) {
-      const int ns5 = nsplit == 23 ? 24 : nsplit;
-      constexpr size_t lds = 2 * (size_t)3 * STEP_BYTES + 2 * RS_BYTES + NWAVE * LST_WAVE_BYTES;
-      if (ns5 == 24) {
-        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_r5_kernel<3, 0, 1>), lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((delta_c1_r5_kernel<3, 0, 1>), dim3(n * ns5), dim3(512), lds, stream, desc,
-                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, ns5, pair0, lidx, live, w1c);
-      } else {
-        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_r5_kernel<3>), lds);
-        if (rc) return rc;
-        hipLaunchKernelGGL((delta_c1_r5_kernel<3>), dim3(n * ns5), dim3(512), lds, stream, desc,
-                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, ns5, pair0, lidx, live, w1c);
-      }
-    } else if (nsplit == 23) {   // a handful of pairs: one row tile per pass, one pass per workgroup
+    if (nsplit == 23) {   // a handful of pairs: one row tile per pass, one pass per workgroup
       rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<1, 3>), t_lds_bytes(3));
       if (rc) return rc;
       hipLaunchKernelGGL((delta_c1_f16x3_kernel<1, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,
                          reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
     } else {
-      static const int spc = getenv("OVN_C1_SPC") ? atoi(getenv("OVN_C1_SPC")) : 3;
-      if (spc == 5) {
-        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<2, 5>), t_lds_bytes(5));
-        if (rc) return rc;
-        hipLaunchKernelGGL((delta_c1_f16x3_kernel<2, 5>), dim3(n * nsplit), dim3(512), t_lds_bytes(5), stream, desc,
-                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
-      } else {
-        rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<2, 3>), t_lds_bytes(3));
-        if (rc) return rc;
-        hipLaunchKernelGGL((delta_c1_f16x3_kernel<2, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,
-                           reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
-      }
+      rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<2, 3>), t_lds_bytes(3));
+      if (rc) return rc;
+      hipLaunchKernelGGL((delta_c1_f16x3_kernel<2, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,
+                         reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
     }
   }
   {
