@@ -900,7 +900,7 @@ def main():
                 eng.spectrum(query_fv, out=query_spec)
                 r = eng.heads(cands[:n_c], query_fv, spec_l=cand_spec[:n_c], spec_r=query_spec,
                               dcache_l=cand_dc[:n_c] if cand_dc is not None else None)
-                return decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3))
+                return decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3, host=True))   # record written to pinned host memory
             for _ in range(5):
                 q_step()
             torch.cuda.synchronize()
@@ -918,7 +918,7 @@ def main():
                                   dcache_l=cand_dc[:n_c] if cand_dc is not None else None)
                     rec = eng.best_match(r["overlap"], r["yaw"], 0.3)
                     qa.submit(query_img, wait_current=False)     # the next query's image is resident: its leg need not wait for these heads
-                    return decode_match(rec)
+                    return decode_match(rec)                     # (device record: the copy overlaps the submit above)
                 for _ in range(5):
                     q_stream()
                 torch.cuda.synchronize()

@@ -928,7 +928,8 @@ __global__ __launch_bounds__(256) void delta_w2sum_kernel(const float* __restric
 // taps 0 .. 14, hi hi / lo hi / hi lo): the results have the bits of the round-5 kernel wherever every column group walks the same
 // slices.  Output: o1raw = -2 M s1r in the streaming order of the c_conv2 kernel (tile of 192 (jb, ib) rows, k-step major; K order of
 // W2p: o' = 4 (o & 15) + (o >> 4)), 16 bytes per lane and accumulator row.  RT = 1 (16 rows x 24 column groups, 22 + 1 passes = 23
-// workgroups per pair) serves a handful of pairs (the single-pair latency of demo2 / gated demo3 queries): same order, same bits.
+// workgroups per pair) and RT = 0 (every pass a short one: 8 rows x 24 column groups, 45 workgroups per pair with 3 tiles per SIMD
+// each) serve a handful of pairs (the single-pair latency of demo2 / gated demo3 queries): same order, same bits.
 constexpr int T_LBLK = 8 * 32 + 16;                       // words of one L block: [8 positions][32 rows] + 16 of padding (bank spread)
 constexpr int T_LSL_WORDS = 4 * T_LBLK;                   // one L slice (32 positions x 32 rows): 4,352 B
 constexpr int T_TAIL_ROW0 = (FW / 16) * 16;               // 352: first row of the short pass
@@ -941,8 +942,8 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
                                                              const f32x4* __restrict__ scales, float* __restrict__ o1raw, int rot,
                                                              int nsplit, int pair0, const int32_t* __restrict__ lidx,
                                                              const unsigned* __restrict__ live, const _Float16* __restrict__ w1c) {
-  constexpr int NFULL = (FW / 16) / RT;          // full passes: 11 (RT 2) / 22 (RT 1)
-  constexpr int NPASS = NFULL + 1;               // + the short pass over rows 352 .. 359
+  constexpr int NFULL = RT ? (FW / 16) / RT : 0; // full passes: 11 (RT 2) / 22 (RT 1); RT 0: none -- EVERY pass is a short one
+  constexpr int NPASS = RT ? NFULL + 1 : FW / 8; // + the short pass over rows 352 .. 359 (RT 0: 45 passes of 8 rows)
   constexpr int T_CHB = T_SPC * STEP_BYTES;      // W1 fragments of a chunk
   constexpr int T_CPS = S / T_SPC;               // chunks per channel slice
   constexpr int T_RCH_WORDS = G * T_SPC * 32;    // R words of a chunk
@@ -1012,10 +1013,10 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 
   int cur = 0, lcur = 0;
   {
-    const bool tail0 = p_begin == NFULL;
+    const bool tail0 = RT == 0 || p_begin == NFULL;
     OVN_DMA_W(T_CPS * s0, 0)
     OVN_DMA_R(s0, 0, 0)
-    OVN_DMA_L(s0, tail0 ? T_TAIL_ROW0 : 16 * RT * p_begin, tail0 ? 8 : 16 * RT, 0)
+    OVN_DMA_L(s0, tail0 ? (RT ? T_TAIL_ROW0 : 8 * p_begin) : 16 * RT * p_begin, tail0 ? 8 : 16 * RT, 0)
   }
   __syncthreads();
 
@@ -1023,13 +1024,13 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   // 16 lanes-rows: column groups jb, jb + 1) x NJ = 2 slots.
   auto run_pass = [&](auto tail_tag, int pass) {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    constexpr int NT = TAIL ? 1 : RT;
+    constexpr int NT = TAIL ? 1 : (RT ? RT : 1);
     constexpr int NJ = TAIL ? 2 : 3;
     const bool has_next = pass + 1 < p_end;
-    const bool next_tail = pass + 1 == NFULL;
-    const int row0_n = next_tail ? T_TAIL_ROW0 : 16 * RT * (pass + 1);
+    const bool next_tail = RT == 0 || pass + 1 == NFULL;
+    const int row0_n = next_tail ? (RT ? T_TAIL_ROW0 : 8 * (pass + 1)) : 16 * RT * (pass + 1);
     const int rows_n = next_tail ? 8 : 16 * RT;
-    const int row0 = TAIL ? T_TAIL_ROW0 : 16 * RT * pass;
+    const int row0 = TAIL ? (RT ? T_TAIL_ROW0 : 8 * pass) : 16 * RT * pass;
     f32x4 acc[NJ][NT][4];
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -1144,7 +1145,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
         for (int r = 0; r < 4; ++r) {
           const int lr = 4 * g + r;
           const int jb = TAIL ? tail_jb0 + 2 * j + (lr >> 3) : 3 * wave + j;
-          const int i = TAIL ? T_TAIL_ROW0 + (lr & 7) : row0 + 16 * t + lr;
+          const int i = TAIL ? row0 + (lr & 7) : row0 + 16 * t + lr;
           const int ib = i / S, di = i - ib * S;
           float* dst = o1raw + ((size_t)pair * 3 + (jb >> 3)) * (C2_TILE_ROWS * K2) + (size_t)(2 * di + (lrow >> 3)) * (C2_TILE_ROWS * 32) +
                        ((jb & 7) * G + ib) * 32 + 4 * (lrow & 7);
@@ -1156,8 +1157,12 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   };
 
   for (int pass = p_begin; pass < p_end; ++pass) {
-    if (pass < NFULL) run_pass(std::false_type{}, pass);
-    else run_pass(std::true_type{}, pass);
+    if constexpr (RT != 0) {
+      if (pass < NFULL) run_pass(std::false_type{}, pass);
+      else run_pass(std::true_type{}, pass);
+    } else {
+      run_pass(std::true_type{}, pass);
+    }
   }
 #undef OVN_DMA_L
 #undef OVN_DMA_W
@@ -1320,8 +1325,10 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right) {
 static int pick_nsplit(int n) {
   // divisors of the 12 passes (11 of two row tiles + the short one): time ~ rounds of workgroups over the 256 CUs x 1/d of a pair's
   // work; the smallest d within 5 % of the best (big sweeps keep d = 1: one workgroup per pair).  d = 23 (ONE row tile per pass, 22 + 1
-  // passes, one per workgroup) only for <= 10 pairs, where the 230 workgroups still fit ONE round: such a workgroup walks the whole
-  // K / W1 stream like a two-tile pass does, so it does not cost half of one and loses as soon as it adds a round
+  // passes, one per workgroup) only for <= 10 pairs and d = 45 (8-row passes) for <= 5, where the workgroups still fit ONE round: such
+  // a workgroup walks the whole K / W1 stream like a two-tile pass does, so it does not cost a fraction of one and loses as soon as it
+  // adds a round
+  if (n <= 5) return 45;
   double best = 1e30;
   auto cost = [n](int d) { return (double)(((long long)n * d + 255) / 256) / d; };
   auto allowed = [n](int d) { return d < 23 || n <= 10; };
@@ -1367,7 +1374,7 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   const unsigned* live = (ridx || !ctx->head_compact) ? nullptr : live_buf;
   ctx->dbg_live = live;   // ovn_head_walk_stats: the K walk of the most recent sweep (its last chunk)
   *o2max_out = o2max;
-  const int nsplit = pick_nsplit(n);   // 23: one row tile per pass and one pass per workgroup, chosen for <= 10 pairs
+  const int nsplit = pick_nsplit(n);   // 45 / 23: 8-row / one-row-tile passes, one per workgroup, chosen for <= 5 / <= 10 pairs
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
     hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
@@ -1385,7 +1392,12 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   }
   {
     OvnProfScope ps(ctx, OVN_K_DELTA, stream);
-    if (nsplit == 23) {   // a handful of pairs: one row tile per pass, one pass per workgroup
+    if (nsplit == 45) {   // up to five pairs: 8-row passes, one per workgroup
+      rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<0, 3>), t_lds_bytes(3));
+      if (rc) return rc;
+      hipLaunchKernelGGL((delta_c1_f16x3_kernel<0, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,
+                         reinterpret_cast<const _Float16*>(ctx->w1p_h), scales, o1raw, 1, nsplit, pair0, lidx, live, w1c);
+    } else if (nsplit == 23) {   // a handful of pairs: one row tile per pass, one pass per workgroup
       rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_c1_f16x3_kernel<1, 3>), t_lds_bytes(3));
       if (rc) return rc;
       hipLaunchKernelGGL((delta_c1_f16x3_kernel<1, 3>), dim3(n * nsplit), dim3(512), t_lds_bytes(3), stream, desc,

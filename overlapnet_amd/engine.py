@@ -315,19 +315,29 @@ class OvnEngine:
 
     # -- loop-closure decision -----------------------------------------------------------------------
     def best_match(self, overlap: torch.Tensor, yaw: Optional[torch.Tensor] = None, threshold: float = 0.3,
-                   ids: Optional[torch.Tensor] = None, index_offset: int = 0) -> torch.Tensor:
+                   ids: Optional[torch.Tensor] = None, index_offset: int = 0, host: bool = False) -> torch.Tensor:
         """On-device `argmax overlap, > threshold` of demo3 (demo3_lcd.py:117-120).  Returns a 4 x int32 device
-        record {candidate id, float bits of overlap, yaw, found}; decode with `decode_match`."""
+        record {candidate id, float bits of overlap, yaw, found}; decode with `decode_match`.  host=True: the kernel writes the
+        record straight into pinned host memory (device-visible at the same address) and the call waits for the stream -- the
+        caller reads the decision without a device-to-host copy (one blit kernel and its hand-off less per query)."""
         n = int(overlap.numel())
         for t, what, dt in ((overlap, "overlap", torch.float32), (yaw, "yaw", torch.int32), (ids, "ids", torch.int32)):
             if t is None:
                 continue
             if t.device != self.device or t.dtype != dt or not t.is_contiguous() or t.numel() != n:
                 raise _lib.OvnError("%s must be a contiguous %s tensor of %d elements on %s" % (what, dt, n, self.device))
-        out = torch.empty(4, dtype=torch.int32, device=self.device)
+        if host:
+            if getattr(self, "_match_host", None) is None:
+                self._match_host = torch.empty(4, dtype=torch.int32).pin_memory()
+            out = self._match_host
+        else:
+            out = torch.empty(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ovn_best_match(self._h, _ptr(overlap), _ptr(yaw), _ptr(ids), n, float(threshold),
                                                int(index_offset), _ptr(out), self._stream()), "ovn_best_match")
+            if host:
+                torch.cuda.current_stream(self.device).synchronize()
+                return out.clone()
         return out
 
     # -- preprocessing ------------------------------------------------------------------------------

@@ -596,6 +596,7 @@ def test_best_match_on_device(engines):
         for thr in (0.3, 0.999):
             want = (k, float(ov[k]), int(yaw[k])) if ov[k] > thr else None
             assert decode_match(e.best_match(t_ov, t_yaw, thr)) == want
+            assert decode_match(e.best_match(t_ov, t_yaw, thr, host=True)) == want      # record written into pinned host memory
             rec = e.best_match(t_ov, t_yaw, thr, ids=t_ids).cpu().numpy()
             assert rec[0] == ids[k] and rec[1:2].view(np.float32)[0] == ov[k] and rec[2] == yaw[k] and rec[3] == int(ov[k] > thr)
         assert e.best_match(t_ov, t_yaw, 0.0, index_offset=1000).cpu().numpy()[0] == 1000 + k
