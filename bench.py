@@ -588,7 +588,7 @@ def main():
     # dead-channel compaction (ovn_set_head_compaction): the contraction walks ceil(live / 32) of the 4 channel slices, where `live`
     # counts the channels that are non-zero somewhere in the QUERY's 360 columns -- measured here on the queries of the timed stream
     # (BEFORE the timed region -- the launches after it stay full-size sweeps, which the traffic passes read --
-    #  read back from the library after an untimed sweep per query: ovn_head_walk_stats -- slices walked by each of the 12 passes)
+    #  read back from the library after an untimed sweep per query: ovn_head_walk_stats -- the slices every wave of the contraction kernel walks)
     live_counts, walks = [], []
     if args.mode == "warm" and args.head_precision == "f16x3" and spectral and P > 0:
         n_w = min(P, 32)
@@ -690,8 +690,9 @@ def main():
                      "query_live_channels": (sum(live_counts) / len(live_counts)) if live_counts else None,
                      "k_walk_frac": walk_frac,
                      "k_walk_by_query": {"live_channels": live_counts, "k_walk_frac": walks,
-                                         "note": "the eight scans of the timed query stream; k_walk_frac = slices of 32 channels walked by "
-                                                 "the 12 passes of the contraction / 48 (ovn_head_walk_stats)"} if walks else None,
+                                         "note": "the eight scans of the timed query stream; k_walk_frac = MFMAs the contraction kernel issues / those of "
+                                                 "the 128-channel walk (a wave skips a 32-channel slice none of its three column "
+                                                 "groups walks; ovn_head_walk_stats)"} if walks else None,
                      "delta_total_ms": sum(prof[k][0] / max(prof[k][1], 1) for k in ("delta_prep", "delta_c12", "delta_c2") if k in prof),
                      "note": rl_note + ("; the next query's leg kernels run on a second stream beside this kernel (QueryAhead): its event "
                                         "time includes the CUs they take at its round boundaries" if qa is not None else "")},

@@ -261,11 +261,12 @@ int ovn_debug_conv(ovn_ctx* ctx, int layer, const float* in_dev, int nb, int h, 
  * (generateNet.py:102-110 intermediates; the reference exposes them as Keras layer outputs.) */
 int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3_dev, void* stream);
 
-/* Measurement hook: the K walk the Delta head's contraction took in the most recent 1-vs-N sweep on this context (its last chunk).
- * out16_host (HOST memory, 16 x int32): [0] largest number of 32-channel slices any pass walked (1..4), [1] channels of the query
- * that are non-zero somewhere in its 360 columns, [2..13] slices walked by passes 0..11 (one pass = two column groups of c_conv1,
- * generateNet.py:96-100), [14] 1 if the dead-channel compaction applied (ovn_set_head_compaction), else 0 and every entry says
- * 4 slices / 128 channels.  Synchronises `stream`.  bench.py reports roofline.k_walk_frac from it. */
+/* Measurement hook: the K walk of the Delta head's contraction in the most recent 1-vs-N sweep on this context (its last chunk).
+ * out16_host (HOST memory, 16 x int32): [0] slices of 32 channels a pass of the contraction kernel walks (1..4: the largest count
+ * below), [1] channels of the query that are non-zero somewhere in its 360 columns, [2..13] slices the live channels of column-group
+ * pairs 0..11 need (a pair = two column groups of c_conv1, generateNet.py:96-100; a wave skips a slice none of its column groups
+ * walks), [14] 1 if the dead-channel compaction applied (ovn_set_head_compaction), else 0 and every entry says 4 slices / 128
+ * channels.  Synchronises `stream`.  bench.py reports roofline.k_walk_frac from it. */
 int ovn_head_walk_stats(ovn_ctx* ctx, int32_t* out16_host, void* stream);
 
 /* Device scratch currently held by the context, in bytes (grows on demand, freed by ovn_destroy). */

@@ -1145,7 +1145,7 @@ def test_dead_channel_compaction_of_the_query(engines):
                 keep[11] = False
         else:
             # nested live sets: 20 channels alive in every column-group pair, 30 more from pair 3 on, 30 more from pair 6 on, 30 more
-            # from pair 9 on -> the list orders them by that count and passes 0-2 / 3-5 / 6-8 / 9-11 walk 1 / 2 / 3 / 4 slices
+            # from pair 9 on -> the list orders them by that count and column-group pairs 0-2 / 3-5 / 6-8 / 9-11 need 1 / 2 / 3 / 4 slices
             perm = rng.permutation(128)
             keep = np.zeros((12, 128), bool)
             keep[:, perm[:20]] = True
@@ -1166,7 +1166,8 @@ def test_dead_channel_compaction_of_the_query(engines):
         if trial == 6:
             sweep(q, True)
             st = e.head_walk_stats()          # the walk the kernel really took (ovn_head_walk_stats)
-            assert st["compacted"] and st["slices_per_pass"] == [1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4] and st["live_channels"] == 110, st
+            assert st["compacted"] and st["slices_per_group_pair"] == [1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4] and st["live_channels"] == 110, st
+            assert st["max_slices"] == 4 and abs(st["k_walk_frac"] - (1 + 1 + 2 + 2 + 3 + 3 + 4 + 4) / 32.0) < 1e-9, st
         # a sweep of 3 candidates (half-pass workgroups) has the bits of the big one
         e.set_head_compaction(True)
         dq = torch.from_numpy(q).cuda()
