@@ -615,6 +615,16 @@ def main():
                 streamed_same = bool(torch.equal(rs[0], res[0]) and torch.equal(rs[1], res[1]))
         torch.cuda.synchronize()
 
+    # ---- census of the ranks (so that the first real multi-GPU line certifies itself): every rank reports the device it runs on;
+    #      rank 0 puts backend, RCCL version, ranks seen and distinct devices into the line ----
+    census = None
+    if use_dist:
+        pr = torch.cuda.get_device_properties(dev)
+        mine_c = {"rank": rank, "local_rank": local_rank, "device": pr.name, "arch": getattr(pr, "gcnArchName", ""),
+                  "pci_bus_id": getattr(pr, "pci_bus_id", None), "uuid": str(getattr(pr, "uuid", "")), "pid": os.getpid()}
+        census = [None] * world
+        dist.all_gather_object(census, mine_c)
+
     # ---- sharded pool: EVERY rank re-evaluates three windows of its block WITHOUT the Delta cache rows (same bits required; windows
     #      beyond the first 1024-pair chunk where the block is long enough) and rank 0 collects the verdicts ----
     shard_check = None
@@ -700,6 +710,19 @@ def main():
         "head_hbm_gbps_algorithmic": (pairs / elapsed) * CAND_BYTES_PER_PAIR / 1e9,
     }
 
+    if census is not None:
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        devs = {(c["local_rank"], c["pci_bus_id"], c["uuid"]) for c in census}
+        out["distributed"] = {"backend": dist.get_backend(), "rccl_version": rccl, "world_size": world,
+                              "ranks_seen": sorted(c["rank"] for c in census), "distinct_devices": len(devs),
+                              "one_rank_per_gpu": bool(len(devs) == world and not rehearsal),
+                              "devices": [c["device"] for c in census], "archs": sorted({c["arch"] for c in census}),
+                              "note": ("%d rank(s) seen over %s; " % (len(census), dist.get_backend())) +
+                                      ("all ranks on ONE device (rehearsal)" if rehearsal else "%d distinct GPUs" % len(devs))}
+        print("[bench] %s" % out["distributed"]["note"], "RCCL", rccl, file=sys.stderr, flush=True)
     if rehearsal:
         # ---- the gathered sweep of query 0 against ONE process evaluating the whole pool: must be the same bits ----
         pool_all = torch.empty((n_total, 360, 128), dtype=torch.float32, device=dev)

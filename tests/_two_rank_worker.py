@@ -134,12 +134,67 @@ def infer_api(work):
     return report
 
 
+def infer_demo3(work):
+    """the reference's REAL caller at world 8 -- the calls its own demo3_lcd.py made on a 259-frame run (recorded in
+    tests/golden/demo_transcript.json: `infer_multiple(frame, gated reference list)`, windows of consecutive frame ids, 83 non-empty
+    lists) replayed through `Infer(config, rank=, world=)` on every rank; every 7th non-empty query goes through `infer_best_match`
+    instead.  Rank 0 replays the same calls on the unsharded object and compares every return value; every rank reports the pairs it
+    scored (`sharded_stats`) so that the test can assert the work shares of the run itself."""
+    from overlapnet_amd.infer import Infer
+    from overlapnet_amd import distributed as D
+    rank, world = dist.get_rank(), dist.get_world_size()
+    cfg = json.load(open(os.path.join(work, "config.json")))
+    w = S.make_test_weights(4, seed=0)
+    cfg.pop("_frames")
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demo_transcript.json")) as fh:
+        events = [e for e in json.load(fh)["demo3"] if e.get("event") == "infer_multiple"]
+    sh = Infer(json.loads(json.dumps(cfg)), weights=w, rank=rank, world=world)
+    ref = Infer(json.loads(json.dumps(cfg)), weights=w) if rank == 0 else None
+    report = {"calls": 0, "mismatch": [], "nonempty": 0, "best_calls": 0, "owner_work": None}
+    work_by_rank = np.zeros(world, np.int64)
+    worst_share = 0.0
+    for e in events:
+        cur, refs = int(e["cur"]), [int(x) for x in e["refs"]]
+        best = bool(refs) and report["nonempty"] % 7 == 3
+        if refs:
+            report["nonempty"] += 1
+            cnt = np.bincount(D.frame_owner(np.asarray(refs), world), minlength=world)
+            work_by_rank += cnt
+            worst_share = max(worst_share, float(cnt.max()) / (len(refs) / world))
+        if best:
+            a = sh.infer_best_match(cur, refs, 0.3)
+            report["best_calls"] += 1
+            if rank == 0:
+                b = ref.infer_best_match(cur, refs, 0.3)
+                if a != b:
+                    report["mismatch"].append(["best", cur])
+        else:
+            a = sh.infer_multiple(cur, refs)
+            if rank == 0:
+                b = ref.infer_multiple(cur, refs)
+                same = (a is None and b is None) or (a is not None and b is not None and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                                                     and a[0].shape == b[0].shape and a[1].dtype == b[1].dtype)
+                if not same:
+                    report["mismatch"].append(["multiple", cur])
+        report["calls"] += 1
+    stats = [None] * world
+    dist.all_gather_object(stats, [len(sh.feature_volumes), dict(sh.sharded_stats)])
+    report["stats"] = [s_[1] for s_ in stats]
+    report["local_frames"] = [s_[0] for s_ in stats]
+    report["owner_work"] = work_by_rank.tolist()                     # pairs each rank owns over the whole run (host arithmetic)
+    report["worst_single_query_share"] = worst_share                 # max over queries of (largest rank share / even share)
+    sh.close()
+    if ref is not None:
+        ref.close()
+    return report
+
+
 def main():
     scenario, work = sys.argv[1], sys.argv[2]
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     try:
-        out = {"engine_sweep": engine_sweep, "infer_api": infer_api}[scenario](work)
+        out = {"engine_sweep": engine_sweep, "infer_api": infer_api, "infer_demo3": infer_demo3}[scenario](work)
         if dist.get_rank() == 0:
             json.dump(out, open(os.path.join(work, "result.json"), "w"))
         dist.barrier()

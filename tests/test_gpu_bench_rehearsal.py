@@ -33,3 +33,9 @@ def test_eight_rank_bench_rehearsal_on_one_gpu():
     assert blocks[0][0] == 0 and blocks[-1][1] == 16384 and all(b[0] % 32 == 0 for b in blocks)
     assert all(blocks[i][1] == blocks[i + 1][0] for i in range(7))
     assert r["config"]["pairs_per_step"] == 16384 and r["overlap_maxerr_vs_oracle"] < 1e-4 and r["yaw_exact_rate"] == 1.0
+    # the census every multi-rank line carries: ranks seen, backend, RCCL version, distinct devices -- here eight
+    # ranks on ONE device, which the line says itself
+    d = r["distributed"]
+    assert d["ranks_seen"] == list(range(8)) and d["world_size"] == 8 and d["backend"] == "gloo"
+    assert d["distinct_devices"] == 1 and d["one_rank_per_gpu"] is False and d["rccl_version"]
+    assert "8 rank(s) seen" in p.stderr

@@ -23,11 +23,11 @@ def _free_port():
     return p
 
 
-def _run_two(scenario, work, timeout=600):
+def _run_two(scenario, work, timeout=600, world=2):
     port = _free_port()
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="4")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), scenario, str(work)],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -81,3 +81,34 @@ def test_sharded_infer_equals_the_unsharded_object(tmp_path, fixture_npz):
     assert r["retry_ok"] is True      # the failed frame did not count as fed: fed again after the repair, then referenced by the next frame
     assert r["order_error"] is True and r["reset_ok"] is True
     assert len(r["best"]) == frames // 5 and any(b[0] is not None for b in r["best"])
+
+
+def test_eight_ranks_replay_the_recorded_demo3_run(tmp_path, fixture_npz):
+    """Rehearsal of the multi-GPU form of the reference's real caller: EIGHT ranks (one GPU, gloo / host collectives --
+    RCCL refuses two ranks on one device; no N > 1 RCCL run exists) replay the 259 `infer_multiple` calls the reference's own
+    demo3_lcd.py made (gated windows of consecutive frame ids, tests/golden/demo_transcript.json) through `Infer(config, rank=, world=8)`,
+    some of them as `infer_best_match`: every return value equals the unsharded object's, every scored pair ran on its owner's cache
+    rows, and the work shares of THIS run stay within the bound DESIGN.md section 7 quotes for the skewed block-cyclic ownership."""
+    from tools import synthetic as S
+    frames = 259
+    seq = tmp_path / "data" / "07"
+    for sub in ("depth", "normal"):
+        os.makedirs(seq / sub)
+    for i in range(frames):
+        s, shift = i % 2, (37 * i) % 900
+        np.save(seq / "depth" / ("%06d.npy" % i), np.roll(fixture_npz["range_%d" % s], shift, axis=1))
+        np.save(seq / "normal" / ("%06d.npy" % i), np.roll(fixture_npz["normal_%d" % s], shift, axis=1))
+    cfg = {"model": dict(S.REFERENCE_MODEL_CFG, inputShape=[64, 900]), "infer_seqs": "07", "data_root_folder": str(tmp_path / "data"),
+           "use_depth": True, "use_normals": True, "use_class_probabilities": False, "use_class_probabilities_pca": False,
+           "use_intensity": False, "batch_size": 16, "pretrained_weightsfilename": "", "_frames": frames}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    r = _run_two("infer_demo3", tmp_path, timeout=900, world=8)
+    assert r["calls"] == 259 and r["nonempty"] == 83 and r["best_calls"] >= 10 and r["mismatch"] == [], r
+    st = r["stats"]
+    assert sum(s["frames_cached"] for s in st) == 259 and max(s["frames_cached"] for s in st) - min(s["frames_cached"] for s in st) <= 3, st
+    assert all(s["pairs_on_cache_rows"] == s["pairs_scored"] for s in st), st
+    scored = np.array([s["pairs_scored"] for s in st], np.float64)
+    assert scored.sum() == 1460 and list(scored.astype(int)) == r["owner_work"], (scored, r["owner_work"])
+    # work-weighted imbalance of the whole run (max / mean share over the ranks) and the worst single query against its even share
+    assert scored.max() / scored.mean() <= 1.31, scored
+    assert r["worst_single_query_share"] <= 4.0, r["worst_single_query_share"]      # (a 2-element list on 8 ranks: 1 of 0.25)
