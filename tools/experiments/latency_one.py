@@ -20,7 +20,7 @@ def step():
     q = eng.leg(query)
     qs = eng.spectrum(q)
     r = eng.heads(pool, q, spec_l=spec, spec_r=qs, dcache_l=dc)
-    return decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3))
+    return decode_match(eng.best_match(r["overlap"], r["yaw"], 0.3, host=True))
 for _ in range(5): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
