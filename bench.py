@@ -117,7 +117,7 @@ def _measured_traffic(kernel_prefix: str, extra_args, timeout_s: float = 150.0):
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out_dir = os.path.join(tmp, ctr)
             cmd = [exe, "--kernel-trace", "--pmc", ctr, "-d", out_dir, "-o", "bench", "--", sys.executable, os.path.abspath(__file__),
-                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--traffic", "none"] + list(extra_args)
+                   "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--no-walk-stats", "--traffic", "none"] + list(extra_args)
             env = dict(os.environ, TMPDIR="/tmp")
             try:
                 p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -396,6 +396,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-query", action="store_true", help="warm mode: the query leg on the heads' stream, in front of them (no QueryAhead)")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32_mode / cold / fullstack / corr_head sub-records")
+    ap.add_argument("--no-walk-stats", action="store_true",
+                    help="skip the untimed 32-pair sweeps that read the K walk of each query of the stream back (profiling runs: every "
+                         "launch of the trace is then a full sweep)")
     ap.add_argument("--rehearsal", action="store_true", default=os.environ.get("OVN_BENCH_REHEARSAL", "") == "1",
                     help="N > 1 ranks on ONE device, gloo / host collectives: rehearses the driver's multi-GPU command path (no pairs/s claim)")
     ap.add_argument("--traffic", default="measure", choices=["measure", "committed", "none"],
@@ -590,7 +593,7 @@ def main():
     # (BEFORE the timed region -- the launches after it stay full-size sweeps, which the traffic passes read --
     #  read back from the library after an untimed sweep per query: ovn_head_walk_stats -- the slices every wave of the contraction kernel walks)
     live_counts, walks = [], []
-    if args.mode == "warm" and args.head_precision == "f16x3" and spectral and P > 0:
+    if args.mode == "warm" and args.head_precision == "f16x3" and spectral and P > 0 and not args.no_walk_stats:
         n_w = min(P, 32)
         for qi in query_ring:
             fq = eng.leg(qi)

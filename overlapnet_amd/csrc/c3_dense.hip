@@ -37,7 +37,7 @@ constexpr int PLANE = IN_PIX_MAX * 8 + 8;                  // fp16 elements per 
                                                            // planes a wave writes at once start in different banks (3840 B apart they all hit
                                                            // bank 0; the fragment reads are unaffected: 0.637 -> 0.625 ms in one run)
 constexpr int NPL = CI / 8;                                // 16 planes
-constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 64;   // hi + lo images + reduction scratch
+constexpr size_t LDS_BYTES = 2 * (size_t)NPL * PLANE * sizeof(_Float16) + 64;   // hi + lo images + reduction scratch (16 floats)
 constexpr int NW = 8;                    // waves that split the 256 output channels (2 n-tiles each)
 
 __device__ __forceinline__ int band_start(int b) { return b == 0 ? 0 : (b == 1 ? 8 : 15); }
@@ -46,11 +46,13 @@ __device__ __forceinline__ int band_rows(int b) { return b == 0 ? 8 : 7; }
 // `o2max` (n) holds the float bits of each pair's max o2 value (written by the Delta kernel's epilogue); the patch is scaled by
 // s2 = 2^14 / 2^ceil(log2 max) before the split, the weights were scaled by `sw3` when they were registered, and the
 // accumulators are divided by s2 * sw3 (powers of two: exact).
-// NWV waves per workgroup: 8 (one workgroup per band: sweeps), or 4 (TWO workgroups per band, each with half of the output channels and
-// its own copy of the patch: one wave per SIMD instead of two -- a handful of pairs are 3 workgroups per pair deep in their own MFMA
-// time, 49 us for a single pair).  The Dense partial sums leave the kernel per (band, half) in both builds and are combined in one
-// fixed order by dense_finish_kernel: same bits.
-template <class A, int NWV>
+// NWV waves per workgroup and MSPLIT workgroups along the m-tiles: <8, 1> (one workgroup per band: sweeps), or <4, 2> (FOUR workgroups
+// per band -- half of the output channels x tiles 0 .. 5 / 6 .. 10, each with its own copy of the patch, one wave per SIMD: a handful
+// of pairs are a few workgroups per pair deep in their own MFMA time; one workgroup per band 49 us for a single pair, two 37 us, four
+// 23 us).  The Dense partial sums leave the kernel per (band, channel half, m-tile half) in both builds -- the sweep build keeps two
+// sums per thread, split at tile MT_SPLIT -- and are combined in one fixed order by dense_finish_kernel: same bits.
+constexpr int MT_SPLIT = 6;
+template <class A, int NWV, int MSPLIT>
 __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restrict__ o2, const typename A::elem* __restrict__ wp,
                                                            const float* __restrict__ b3, const float* __restrict__ wd,
                                                            const unsigned* __restrict__ o2max, float sw3,
@@ -64,7 +66,10 @@ __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restr
   float* red = reinterpret_cast<float*>(il + NPL * PLANE);
 
   constexpr int HALVES = NW / NWV;
-  const int unit = blockIdx.x / HALVES, half = blockIdx.x - unit * HALVES;
+  constexpr int MTW = MSPLIT == 1 ? MAX_MT : MT_SPLIT;        // m-tile slots of this workgroup
+  const int sub = blockIdx.x % (HALVES * MSPLIT);
+  const int unit = blockIdx.x / (HALVES * MSPLIT), half = sub % HALVES, mh = sub / HALVES;
+  const int mt0 = MT_SPLIT * mh;                              // first m-tile of this workgroup
   const int pair = unit / NBAND;
   const int band = unit - pair * NBAND;
   const int r0 = band_start(band);
@@ -127,19 +132,19 @@ __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restr
   }
 
   // per m-tile: LDS offset of this lane's output pixel at tap (0,0), channel group 8g
-  int abase[MAX_MT];
+  int abase[MTW];
 #pragma unroll
-  for (int mt = 0; mt < MAX_MT; ++mt) {
-    int p = 16 * mt + lrow;
+  for (int mt = 0; mt < MTW; ++mt) {
+    int p = 16 * (mt0 + mt) + lrow;
     if (p >= npix) p = npix - 1;               // padded rows of the last tile recompute the last pixel (never stored)
     const int oy = p / OW;
     const int ox = p - oy * OW;
     abase[mt] = g * PLANE + (oy * G + ox) * 8;
   }
 
-  f32x4 acc[MAX_MT][2];
+  f32x4 acc[MTW][2];
 #pragma unroll
-  for (int mt = 0; mt < MAX_MT; ++mt) {
+  for (int mt = 0; mt < MTW; ++mt) {
     acc[mt][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     acc[mt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -170,26 +175,26 @@ __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restr
     v8_t fh[2][2], fl[2][2];                                                              \
     C3_READ_A(0, 0, 0)                                                                      \
     C3_READ_A(0, 1, 1)                                                                      \
-    _Pragma("unroll") for (int q = 0; q < MAX_MT / 2; ++q) {                                \
+    _Pragma("unroll") for (int q = 0; q < MTW / 2; ++q) {                                \
       const int cb = q & 1, nb = cb ^ 1;                                                    \
-      if (q + 1 < MAX_MT / 2) {                                                             \
+      if (q + 1 < MTW / 2) {                                                             \
         C3_READ_A(nb, 0, 2 * q + 2)                                                         \
         C3_READ_A(nb, 1, 2 * q + 3)                                                         \
-      } else if (nmt == MAX_MT) {                                                           \
-        C3_READ_A(nb, 0, MAX_MT - 1)                                                        \
+      } else if (MTW % 2 == 1 && nmt == MAX_MT) {                                                           \
+        C3_READ_A(nb, 0, MTW - 1)                                                        \
       }                                                                                     \
       __builtin_amdgcn_sched_barrier(0);  /* keep the reads ahead of the MFMAs they do not feed */ \
       C3_MFMA2(2 * q, 2 * q + 1, fh[cb][0], fl[cb][0], fh[cb][1], fl[cb][1], SRC)           \
       __builtin_amdgcn_sched_barrier(0);                                                    \
     }                                                                                       \
-    if (nmt == MAX_MT) {  /* the 8-row band has an 11th tile */                             \
-      const v8_t ah = fh[(MAX_MT / 2) & 1][0], al = fl[(MAX_MT / 2) & 1][0];              \
-      acc[MAX_MT - 1][0] = A::mfma(ah, SRC[0], acc[MAX_MT - 1][0]); \
-      acc[MAX_MT - 1][1] = A::mfma(ah, SRC[2], acc[MAX_MT - 1][1]); \
-      acc[MAX_MT - 1][0] = A::mfma(al, SRC[0], acc[MAX_MT - 1][0]); \
-      acc[MAX_MT - 1][1] = A::mfma(al, SRC[2], acc[MAX_MT - 1][1]); \
-      acc[MAX_MT - 1][0] = A::mfma(ah, SRC[1], acc[MAX_MT - 1][0]); \
-      acc[MAX_MT - 1][1] = A::mfma(ah, SRC[3], acc[MAX_MT - 1][1]); \
+    if (MTW % 2 == 1 && nmt == MAX_MT) {  /* the 8-row band has an 11th tile */                             \
+      const v8_t ah = fh[(MTW / 2) & 1][0], al = fl[(MTW / 2) & 1][0];              \
+      acc[MTW - 1][0] = A::mfma(ah, SRC[0], acc[MTW - 1][0]); \
+      acc[MTW - 1][1] = A::mfma(ah, SRC[2], acc[MTW - 1][1]); \
+      acc[MTW - 1][0] = A::mfma(al, SRC[0], acc[MTW - 1][0]); \
+      acc[MTW - 1][1] = A::mfma(al, SRC[2], acc[MTW - 1][1]); \
+      acc[MTW - 1][0] = A::mfma(ah, SRC[1], acc[MTW - 1][0]); \
+      acc[MTW - 1][1] = A::mfma(ah, SRC[3], acc[MTW - 1][1]); \
     }                                                                                       \
   }
   __syncthreads();  // patch complete
@@ -207,38 +212,47 @@ __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restr
 #undef C3_MFMA2
 #undef C3_READ_A
 
-  // ---- epilogue: bias + ReLU, optional o3 store, Dense partial.  C/D: lane holds channel lrow of each n-tile, rows 4g..4g+3
-  float s = 0.f;
+  // ---- epilogue: bias + ReLU, optional o3 store, Dense partials (tiles below / from MT_SPLIT).  C/D: lane holds channel lrow of each
+  //      n-tile, rows 4g..4g+3
+  float s[2] = {0.f, 0.f};
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int n = 32 * wave + 16 * nt + lrow;
     const float bv = b3[n];
 #pragma unroll
-    for (int mt = 0; mt < MAX_MT; ++mt) {
+    for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int p = 16 * mt + 4 * g + r;
+        const int p = 16 * (mt0 + mt) + 4 * g + r;
         if (p < npix) {
           const float v = fmaxf(fmaf(acc[mt][nt][r], inv, bv), 0.0f);
           const long long fi = (long long)(r0 * OW + p) * CO + n;     // Flatten index (H, W, C) of this value
-          s += v * wd[fi];
+          s[(MSPLIT == 1 && mt >= MT_SPLIT) ? 1 : 0] += v * wd[fi];
           if (o3) o3[(long long)pair * OVN_DENSE_IN + fi] = v;
         }
       }
     }
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-  if (lane == 0) red[wave_l] = s;
+  for (int off = 32; off > 0; off >>= 1) {
+    s[0] += __shfl_down(s[0], off, 64);
+    if (MSPLIT == 1) s[1] += __shfl_down(s[1], off, 64);
+  }
+  if (lane == 0) {
+    red[wave_l] = s[0];
+    if (MSPLIT == 1) red[NW + wave_l] = s[1];
+  }
   __syncthreads();
-  // partial[pair][band][half of the output channels]: (w0 + w1) + (w2 + w3) of each half
+  // partial[pair][band][half of the output channels][m-tile half]: (w0 + w1) + (w2 + w3) of each channel half
   if (tid == 0) {
-    float* dst = partial + ((size_t)pair * NBAND + band) * 2;
+    float* dst = partial + ((size_t)pair * NBAND + band) * 4;
     if (NWV == NW) {
       dst[0] = (red[0] + red[1]) + (red[2] + red[3]);
-      dst[1] = (red[4] + red[5]) + (red[6] + red[7]);
+      dst[1] = (red[NW + 0] + red[NW + 1]) + (red[NW + 2] + red[NW + 3]);
+      dst[2] = (red[4] + red[5]) + (red[6] + red[7]);
+      dst[3] = (red[NW + 4] + red[NW + 5]) + (red[NW + 6] + red[NW + 7]);
     } else {
-      dst[half] = (red[0] + red[1]) + (red[2] + red[3]);
+      dst[2 * half + mh] = (red[0] + red[1]) + (red[2] + red[3]);
     }
   }
 }
@@ -247,29 +261,36 @@ __global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restri
                                                            float* __restrict__ overlap, float* __restrict__ logit) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= n) return;
-  const float* q = partial + (size_t)p * (2 * NBAND);
-  const float z = (((q[0] + q[1]) + (q[2] + q[3])) + (q[4] + q[5])) + bd[0];   // bands in order, each = its two channel halves
+  const float* q = partial + (size_t)p * OVN_DENSE_PARTIALS;
+  // bands in order; a band = (its two m-tile halves of channel half 0) + (those of channel half 1)
+  float z = 0.f;
+#pragma unroll
+  for (int b = 0; b < NBAND; ++b) {
+    const float zb = (q[4 * b] + q[4 * b + 1]) + (q[4 * b + 2] + q[4 * b + 3]);
+    z = b == 0 ? zb : z + zb;
+  }
+  z += bd[0];
   if (logit) logit[p] = z;
   overlap[p] = 1.0f / (1.0f + expf(-z));
 }
 
 }  // namespace
 
-// o2 (n,24,24,128) fp32 -> partial (6 n) Dense partial sums per (output-row band, half of the output channels) [+ o3 (n,22,22,256) when not NULL];
+// o2 (n,24,24,128) fp32 -> partial (12 n) Dense partial sums per (output-row band, half of the output channels, m-tile half) [+ o3 (n,22,22,256) when not NULL];
 // ovn_dense_finish_forward turns the partials into logit / overlap.
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
                          hipStream_t stream) {
   OVN_REQUIRE(o2max != nullptr, OVN_ERR_ARG, "ovn_c3_dense_forward: the per-pair maxima of o2 are required");
   int rc;
-  if (n <= 42) {   // a handful of pairs: two 4-wave workgroups per band (6 n <= 252 workgroups: still one round, one per CU)
-    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, 4>), LDS_BYTES);
+  if (n <= 21) {   // a handful of pairs: four 4-wave workgroups per band (12 n <= 252 workgroups: still one round, one per CU)
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, 4, 2>), LDS_BYTES);
     if (rc) return rc;
-    hipLaunchKernelGGL((c3_dense_kernel<ArithF16, 4>), dim3(2 * NBAND * n), dim3(64 * 4), LDS_BYTES, stream, o2,
+    hipLaunchKernelGGL((c3_dense_kernel<ArithF16, 4, 2>), dim3(4 * NBAND * n), dim3(64 * 4), LDS_BYTES, stream, o2,
                        reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
   } else {
-    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, NW>), LDS_BYTES);
+    rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, NW, 1>), LDS_BYTES);
     if (rc) return rc;
-    hipLaunchKernelGGL((c3_dense_kernel<ArithF16, NW>), dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
+    hipLaunchKernelGGL((c3_dense_kernel<ArithF16, NW, 1>), dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
                        reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
   }
   OVN_HIP_CHECK(hipGetLastError());

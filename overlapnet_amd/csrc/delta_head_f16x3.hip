@@ -226,14 +226,26 @@ __global__ __launch_bounds__(512) void delta_a2_kernel(const float* __restrict__
   static_assert(K1 % (4 * A2_KSPLIT) == 0 && KS % 4 == 0, "K slices must be whole groups of 4 k-steps");
   const float* R = feats_r + (long long)(ridx ? ridx[b] : 0) * OVN_FEAT_ELEMS;
   const int jb = 16 * mt + lrow;
-  const float* arow = R + (size_t)(jb < G ? jb : G - 1) * K1 + g + 4 * KS * ksl;
-  const float* bcol = w1raw + (size_t)(g + 4 * KS * ksl) * O1 + 16 * nt + lrow;
+  // K order inside a slice: step (j, e) takes k = 16 j + 4 g + e from lane group g -- a lane's four consecutive k are ONE 16-byte load
+  // of its row (the four lane groups of a row read 64 contiguous bytes); k = 4 ks + g, one float per lane and step, made every load
+  // instruction touch 16 rows x 4 bytes at 7.5 KB strides and the kernel address-bound (14 us in front of every sweep).  Any K order
+  // serves as long as A and B agree; chain e sums its 15 steps in order, the chains are combined as before.
+  static_assert(KS % 4 == 0, "a slice is whole groups of 16 k");
+  const float* arow = R + (size_t)(jb < G ? jb : G - 1) * K1 + 4 * KS * ksl + 4 * g;
+  const float* bcol = w1raw + (size_t)(4 * KS * ksl + 4 * g) * O1 + 16 * nt + lrow;
   f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // independent chains
-#pragma unroll 3
-  for (int ks = 0; ks < KS; ks += 4) {
+  f32x4 av[KS / 4];
+  float bv[KS / 4][4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(arow[4 * (ks + u)], bcol[(size_t)4 * (ks + u) * O1], acc[u], 0, 0, 0);
+  for (int j = 0; j < KS / 4; ++j) {
+    av[j] = *reinterpret_cast<const f32x4*>(arow + 16 * j);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bv[j][e] = bcol[(size_t)(16 * j + e) * O1];
+  }
+#pragma unroll
+  for (int j = 0; j < KS / 4; ++j) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], bv[j][e], acc[e], 0, 0, 0);
   }
   const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
@@ -316,38 +328,62 @@ __device__ __forceinline__ int load_chan_table(const unsigned* __restrict__ live
 // walks only up to the last position that is alive in it: nsp[p] = ceil(that / 32) slices.  One list, one set of gathered weights, and
 // a column-group pair whose own live channels fit fewer slices than the query's walks fewer (the benchmark's query: 94 live channels,
 // 3 slices everywhere; under the trained-like weights 99 live -> 4 slices as a whole, but 3 in ten of its twelve pairs).
-// Threads 0 .. 127 take one walk position each; every thread of the workgroup must call it.  `scr`: FC + 16 ints of LDS.
+// Every thread of the (512-thread) workgroup must call it.  `scr`: 2 FC + 32 ints of LDS.
 // Leaves chan_s[0 .. 127] and chan_s[FC + p]; returns the number of live channels.
 __device__ __forceinline__ int build_chan_list(const int (*alive2)[FC], bool shifted, unsigned char* chan_s, int* scr, int tid) {
   int* cnt_s = scr;            // [FC] pairs position q is alive in
-  int* nmax = scr + FC;        // [NPAIR] walk length of pair p; [NPAIR] live channels
-  const int ch = ident_chan(tid & (FC - 1));
+  int* nmax = scr + FC;        // [2 waves][16]: walk length of pair p = 0 .. 11; [12] live channels
+  int* rank_s = scr + FC + 32; // [FC] rank of position q, summed over the four quarters of the comparison range
+  const int pos = tid & (FC - 1), quarter = tid >> 7;   // 512 threads: position x quarter of the positions it is compared with
+  const int ch = ident_chan(pos);
   int cnt = 0;
   if (tid < FC) {
 #pragma unroll
     for (int p = 0; p < NPAIR; ++p) cnt += (shifted || alive2[p][ch] != 0) ? 1 : 0;
     cnt_s[tid] = cnt;
+    rank_s[tid] = 0;
   }
-  if (tid <= NPAIR) nmax[tid] = 0;
   __syncthreads();
-  if (tid < FC) {
-    int rank = 0;
-    for (int q = 0; q < FC; ++q) {
+  cnt = cnt_s[pos];
+  {
+    // (the 128 comparisons of a position as 4 x 32 over the workgroup, reads batched: as one rolled loop on 128 threads every LDS read
+    //  waited for the previous one -- 6 us of a kernel that stands in front of every sweep)
+    int part = 0;
+#pragma unroll 8
+    for (int k = 0; k < FC / 4; ++k) {
+      const int q = (FC / 4) * quarter + k;
       const int cq = cnt_s[q];
-      rank += (cq > cnt || (cq == cnt && q < tid)) ? 1 : 0;
+      part += (cq > cnt || (cq == cnt && q < pos)) ? 1 : 0;
     }
+    if (part) atomicAdd(&rank_s[pos], part);
+  }
+  __syncthreads();
+  if (tid < FC) {   // (waves 0 and 1, whole)
+    const int rank = rank_s[tid];
     chan_s[rank] = (unsigned char)ch;
-    if (cnt > 0) atomicAdd(&nmax[NPAIR], 1);
+    // walk length of every pair and the live count as WAVE reductions (shuffles), one LDS word per wave and quantity: written as LDS
+    // atomics the compiler's atomic optimiser turns each of the 13 into a serial loop over the 64 lanes -- 17 of the kernel's 35 us
+    int v[NPAIR + 1];
 #pragma unroll
-    for (int p = 0; p < NPAIR; ++p)
-      if (shifted || alive2[p][ch] != 0) atomicMax(&nmax[p], rank + 1);
+    for (int p = 0; p < NPAIR; ++p) v[p] = (shifted || alive2[p][ch] != 0) ? rank + 1 : 0;
+    v[NPAIR] = cnt > 0 ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+      for (int p = 0; p < NPAIR; ++p) v[p] = max(v[p], __shfl_xor(v[p], off, 64));
+      v[NPAIR] += __shfl_xor(v[NPAIR], off, 64);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int p = 0; p <= NPAIR; ++p) nmax[16 * (tid >> 6) + p] = v[p];
+    }
   }
   __syncthreads();
   if (tid < 16) {
-    int ns = tid < NPAIR ? (nmax[tid] + 31) / 32 : 0;
+    int ns = tid < NPAIR ? (max(nmax[tid], nmax[16 + tid]) + 31) / 32 : 0;
     chan_s[FC + tid] = (unsigned char)(tid < NPAIR ? (ns < 1 ? 1 : ns) : 4);
   }
-  const int nlive = nmax[NPAIR];
+  const int nlive = nmax[NPAIR] + nmax[16 + NPAIR];
   __syncthreads();
   return nlive;
 }
@@ -357,7 +393,7 @@ __device__ __forceinline__ int build_chan_list(const int (*alive2)[FC], bool shi
 __global__ __launch_bounds__(512) void delta_live_kernel(const float* __restrict__ feats_r, unsigned* __restrict__ live) {
   __shared__ int alive2[NPAIR][FC];
   __shared__ int neg_s;
-  __shared__ int scr[FC + 16];
+  __shared__ int scr[2 * FC + 32];
   __shared__ __attribute__((aligned(16))) unsigned char chan_s[CHAN_BYTES];
   const int tid = threadIdx.x, c = tid & (FC - 1), part = tid >> 7;
   for (int i = tid; i < NPAIR * FC; i += 512) (&alive2[0][0])[i] = 0;
@@ -768,7 +804,7 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
   __shared__ float red[2 * NWAVE];
   __shared__ float A2l[G * O1];
   __shared__ int alive2[NPAIR][FC];
-  __shared__ int scr[FC + 16];
+  __shared__ int scr[2 * FC + 32];
   __shared__ __attribute__((aligned(16))) unsigned char chan_q[CHAN_BYTES];
   const int ver = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -849,29 +885,43 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
     // this workgroup's share of the W1 fragments gathered for the list (workgroups QV .. QV + QGW - 1 do nothing else)
     const int total8 = ns * S * 4 * 2 * 64;
     for (int idx8 = ver * 512 + tid; idx8 < total8; idx8 += gridDim.x * 512) w1c_gather8(w1p, chan_q, idx8, w1c);
-    if (ver >= QV) return;
+    if (ver >= QV && ver != (int)gridDim.x - 1) return;
   } else {
     (void)load_chan_table(nullptr, false, chan_q, tid);
     __syncthreads();
   }
-#pragma unroll 2
-  for (int k = 0; k < 12; ++k) {
-    const int i8 = tid + 512 * k;
-    if (i8 < R_ITEMS) {
-      const int jrow = i8 >> 4, sc = (i8 >> 2) & 3, gq = i8 & 3;
-      if (sc < ns) {
-        const int jb = jrow / S, dj = jrow - jb * S;
-        const float* rrow = feats_r + (size_t)jrow * FC;
-        const unsigned char* ch = chan_q + 32 * sc + 8 * gq;
-        const f32x4 v0 = {rrow[ch[0]], rrow[ch[1]], rrow[ch[2]], rrow[ch[3]]};
-        const f32x4 v1 = {rrow[ch[4]], rrow[ch[5]], rrow[ch[6]], rrow[ch[7]]};
-        unsigned* dst = Pr + ((jb * 4 + sc) * S + dj) * 32 + gq * 8;
-        *reinterpret_cast<u32x4*>(dst) = pack4(v0, sa, 0.0f);
-        *reinterpret_cast<u32x4*>(dst + 4) = pack4(v1, sa, 0.0f);
+  if (ver < QV) {
+    // two phases: ALL 96 channel-gathered loads of a thread first (addresses clamped for the items it will not store: the loads stay
+    // unconditional and in flight together), then packing and stores -- as one load / use loop unrolled by 2 this paid six L2 round
+    // trips in a row, a third of the kernel's 39 us in front of a single-pair sweep
+    f32x4 gv[12][2];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int i8 = tid + 512 * k;
+      const int i8c = i8 < R_ITEMS ? i8 : R_ITEMS - 1;
+      const int jrow = i8c >> 4, sc = (i8c >> 2) & 3, gq = i8c & 3;
+      const float* rrow = feats_r + (size_t)jrow * FC;
+      const unsigned char* ch = chan_q + 32 * (sc < ns ? sc : 0) + 8 * gq;
+      gv[k][0] = (f32x4){rrow[ch[0]], rrow[ch[1]], rrow[ch[2]], rrow[ch[3]]};
+      gv[k][1] = (f32x4){rrow[ch[4]], rrow[ch[5]], rrow[ch[6]], rrow[ch[7]]};
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int i8 = tid + 512 * k;
+      if (i8 < R_ITEMS) {
+        const int jrow = i8 >> 4, sc = (i8 >> 2) & 3, gq = i8 & 3;
+        if (sc < ns) {
+          const int jb = jrow / S, dj = jrow - jb * S;
+          unsigned* dst = Pr + ((jb * 4 + sc) * S + dj) * 32 + gq * 8;
+          *reinterpret_cast<u32x4*>(dst) = pack4(gv[k][0], sa, 0.0f);
+          *reinterpret_cast<u32x4*>(dst + 4) = pack4(gv[k][1], sa, 0.0f);
+        }
       }
     }
   }
-  if (ver != 0) return;
+  // AA and {max, min} are left by the LAST workgroup of the launch (a gather helper when the sweep compacts): workgroup 0's packing and
+  // this dot product run side by side instead of one after the other
+  if (ver != (int)gridDim.x - 1) return;
   float* aa = reinterpret_cast<float*>(qblock + (size_t)QV * OVN_FEAT_ELEMS);
   if (tid == 0) *reinterpret_cast<f32x4*>(aa + G * O2) = (f32x4){mx, mn, 0.f, 0.f};
 #pragma unroll

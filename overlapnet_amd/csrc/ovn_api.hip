@@ -476,8 +476,8 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const size_t o2_bytes = al((size_t)cmax * o2_elems * sizeof(float));
   // second scratch region: o3 (n,22,22,256) in fp32 mode; in f16x3 mode c_conv3 and the Dense layer are one kernel and only
-  // 6 partial sums per pair (band x half of the output channels) leave it
-  const size_t o3_bytes = fused ? al((size_t)cmax * 6 * sizeof(float)) : al((size_t)cmax * o3_elems * sizeof(float));
+  // OVN_DENSE_PARTIALS partial sums per pair (band x half of the output channels x half of the m-tiles) leave it
+  const size_t o3_bytes = fused ? al((size_t)cmax * OVN_DENSE_PARTIALS * sizeof(float)) : al((size_t)cmax * o3_elems * sizeof(float));
   // f16x3 mode: per-pair scales, packed volumes, linear terms and the c_conv1 rows between the two Delta kernels (2.9 MB per pair),
   // one self-contained block per sub-chunk
   const size_t sc_sub = fused ? al(ovn_delta_f16x3_scratch_bytes((int)sub, ridx != nullptr)) : 0;
@@ -526,7 +526,7 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
       float* o2s = o2 + (size_t)q0 * o2_elems;
       if (fused) {   // times its prepare kernels, the contraction kernel and c_conv2 separately
         unsigned* o2max = nullptr;
-        float* part = o3 + (size_t)q0 * 6;
+        float* part = o3 + (size_t)q0 * OVN_DENSE_PARTIALS;
         rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff),
                                           // a cache row belongs to a CANDIDATE: without an index list it moves with the feature pointer
                                           dcache_l ? (lidx ? dcache_l : dcache_l + (size_t)p0 * OVN_DELTA_CACHE_ELEMS) : nullptr);

@@ -69,6 +69,7 @@ constexpr int OVN_C2_OUT = 128;   // c_conv2 filters
 constexpr int OVN_C3_OUT = 256;   // c_conv3 filters
 constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
 constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
+constexpr int OVN_DENSE_PARTIALS = 12;                        // Dense partial sums per pair left by c3_dense_kernel: 3 row bands x 2 channel halves x 2 m-tile halves
 constexpr int OVN_ACTMAX_SLOTS = 32;                           // layers with per-scan activation maxima (f16x3 scales)
 constexpr int OVN_LEG_SLICE = 1024;                             // scans per pass of ovn_leg over its ping-pong scratch
 constexpr int OVN_ACTMAX_STRIDE = 32;                          // words between the maxima of two scans: every scan's word has its
