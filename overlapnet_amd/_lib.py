@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libovn_hip.so")
+# OVN_LIB names another build of the library (same ABI version) -- A/B timing of two builds in one checkout, tools/experiments
+LIB_PATH = os.environ.get("OVN_LIB") or os.path.join(_HERE, "libovn_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 ABI_VERSION = 6

@@ -1033,7 +1033,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   for (int j = 0; j < 3; ++j) ns_full[j] = __builtin_amdgcn_readfirstlane((int)chan_s[FC + ((3 * wave + j) >> 1)]);
   // short pass: waves 0 .. 3 take two tiles (column groups 4 w .. 4 w + 3), waves 4 .. 7 one (16 + 2 (w - 4), + 1): three per SIMD
   const int tail_jb0 = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 * wave : 16 + 2 * (wave - 4));
-  const int tail_slots = wave < 4 ? 2 : 1;
+  const int tail_slots = __builtin_amdgcn_readfirstlane(wave < 4 ? 2 : 1);
 #pragma unroll
   for (int j = 0; j < 2; ++j) ns_tail[j] = __builtin_amdgcn_readfirstlane((int)chan_s[FC + ((tail_jb0 + 2 * j) >> 1)]);
 
@@ -1072,10 +1072,10 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 
   // One pass.  TAIL = false: NT = RT row tiles x NJ = 3 column groups per wave; TAIL = true: one tile row (8 rows, both halves of the
   // 16 lanes-rows: column groups jb, jb + 1) x NJ = 2 slots.
-  auto run_pass = [&](auto tail_tag, int pass) {
-    constexpr bool TAIL = decltype(tail_tag)::value;
+  auto run_pass = [&](auto slots_tag, int pass) {   // tag: 0 = a full pass, 1 / 2 = a short pass of this wave's one / two tiles
+    constexpr bool TAIL = decltype(slots_tag)::value != 0;
     constexpr int NT = TAIL ? 1 : (RT ? RT : 1);
-    constexpr int NJ = TAIL ? 2 : 3;
+    constexpr int NJ = TAIL ? decltype(slots_tag)::value : 3;
     const bool has_next = pass + 1 < p_end;
     const bool next_tail = RT == 0 || pass + 1 == NFULL;
     const int row0_n = next_tail ? (RT ? T_TAIL_ROW0 : 8 * (pass + 1)) : 16 * RT * (pass + 1);
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
       }
       bool act[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) act[j] = TAIL ? (j < tail_slots && sl < ns_tail[j]) : (sl < ns_full[j]);
+      for (int j = 0; j < NJ; ++j) act[j] = TAIL ? (sl < ns_tail[j]) : (sl < ns_full[j]);
       bool any = false;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) any = any || act[j];
@@ -1188,7 +1188,6 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
     // [row = (jb % 8) 24 + ib][o' & 31], o' = 4 lrow + nt: 16 bytes per lane.  The stores drain behind the next pass's first chunk.
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      if (TAIL && j >= tail_slots) continue;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -1206,12 +1205,17 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
     }
   };
 
+  // (the short pass as two instantiations, picked per wave: a slot test inside the chunk would end its scheduling regions, an idle
+  //  second slot in waves 4 .. 7 would be 4 more tiles per pair and the busiest SIMD at 4 instead of 3; every wave meets the same barriers)
   for (int pass = p_begin; pass < p_end; ++pass) {
+    bool full = false;
+    if constexpr (RT != 0) full = pass < NFULL;
     if constexpr (RT != 0) {
-      if (pass < NFULL) run_pass(std::false_type{}, pass);
-      else run_pass(std::true_type{}, pass);
-    } else {
-      run_pass(std::true_type{}, pass);
+      if (full) run_pass(std::integral_constant<int, 0>{}, pass);
+    }
+    if (!full) {
+      if (tail_slots == 2) run_pass(std::integral_constant<int, 2>{}, pass);
+      else run_pass(std::integral_constant<int, 1>{}, pass);
     }
   }
 #undef OVN_DMA_L
