@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "ovn_internal.h"
+#include "delta_a2.h"
 
 namespace {
 
@@ -53,17 +54,28 @@ constexpr int KH = 96;             // threads per frequency half in phase 2 (k =
 constexpr int NK = FW / 4 + 1;     // 91 values of k
 constexpr int F_SPLIT = 90;        // half 0: f = 0..89, half 1: f = 90..180 (+ the zero pad 181)
 
+// A2 = true (small 1-vs-N sweeps): workgroups n_pairs .. n_pairs + 21 of the launch run the 64 wave tasks of the Delta head's
+// right-volume term for the sweep's query instead (delta_a2.h) -- independent of the yaw head, one launch less in a single query's chain.
+constexpr int A2_WGS = (OVN_A2_TASKS + PROD_THREADS / 64 - 1) / (PROD_THREADS / 64);   // 22
+template <bool A2>
 __global__ __launch_bounds__(PROD_THREADS) void spectral_corr_kernel(const float* __restrict__ spec_l,
                                                                     const int32_t* __restrict__ lidx,
                                                                     const float* __restrict__ spec_r,
                                                                     const int32_t* __restrict__ ridx,
                                                                     const double* __restrict__ tw64,   // [2][360]: cos, sin(2 pi m / 360)
-                                                                    int32_t* __restrict__ yaw, float* __restrict__ corr_out) {
+                                                                    int32_t* __restrict__ yaw, float* __restrict__ corr_out,
+                                                                    int n_pairs, const float* __restrict__ a2_feats_r,
+                                                                    const float* __restrict__ a2_w1raw, float* __restrict__ a2raw) {
   __shared__ float part[CG][2][IM_OFF];
   __shared__ __attribute__((aligned(16))) double ab[NF + 1][2];
   __shared__ double half1[NK][4];
   __shared__ float rv[3];
   __shared__ int ri[3];
+  if (A2 && (int)blockIdx.x >= n_pairs) {   // workgroup-uniform
+    const int task = ((int)blockIdx.x - n_pairs) * (PROD_THREADS / 64) + (int)(threadIdx.x >> 6);
+    if (task < OVN_A2_TASKS) ovn_delta_a2_task(a2_feats_r, a2_w1raw, a2raw, task, (int)(threadIdx.x & 63));
+    return;
+  }
   const int pair = blockIdx.x;
   const int tid = threadIdx.x;
   const float* L = spec_l + (long long)(lidx ? lidx[pair] : pair) * OVN_SPEC_ELEMS;
@@ -418,8 +430,14 @@ int ovn_spectrum_forward(ovn_ctx* ctx, const float* feats, int n, float* spectra
 }
 
 int ovn_corr_spectral_forward(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,
-                              const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream) {
-  hipLaunchKernelGGL(spectral_corr_kernel, dim3(n), dim3(PROD_THREADS), 0, stream, spec_l, lidx, spec_r, ridx, ctx->tw64, yaw, corr);
+                              const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream, const float* a2_feats_r,
+                              float* a2raw) {
+  if (a2_feats_r != nullptr && a2raw != nullptr)
+    hipLaunchKernelGGL(spectral_corr_kernel<true>, dim3(n + A2_WGS), dim3(PROD_THREADS), 0, stream, spec_l, lidx, spec_r, ridx,
+                       ctx->tw64, yaw, corr, n, a2_feats_r, ctx->w1raw, a2raw);
+  else
+    hipLaunchKernelGGL(spectral_corr_kernel<false>, dim3(n), dim3(PROD_THREADS), 0, stream, spec_l, lidx, spec_r, ridx, ctx->tw64, yaw,
+                       corr, n, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

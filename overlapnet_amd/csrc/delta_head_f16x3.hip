@@ -43,6 +43,7 @@
 #include <type_traits>
 
 #include "ovn_internal.h"
+#include "delta_a2.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -60,8 +61,8 @@ constexpr int K1 = S * FC;            // 1920
 constexpr int K2 = S * O1;            // 960
 constexpr int STEP_BYTES = 8192;      // W1 fragments of one MFMA step: [nt(4)][hi/lo][lane(64)][8 fp16]
 constexpr int NWAVE = 8;
-constexpr int A2_ELEMS = G * O1;                   // floats of A2 per right volume [jb][o]
-constexpr int A2_KSPLIT = 8;                       // K slices (workgroups) per right volume in delta_a2_kernel
+constexpr int A2_ELEMS = OVN_A2_ELEMS;             // floats of A2 per right volume and K slice [jb][o] (delta_a2.h)
+constexpr int A2_KSPLIT = OVN_A2_KSPLIT;           // K slices (workgroups) per right volume in delta_a2_kernel
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -212,47 +213,13 @@ __global__ void delta_prep_w2_f16_kernel(const float* __restrict__ w2, _Float16*
   }
 }
 
-// A2raw[v][ksl][jb][o] = partial sums over K slice ksl of sum_{dj,c} R_v[15 jb + dj][c] W1[dj][c][o] for right volume v
-// (v = ridx[b] if ridx else 0), on the fp32 matrix cores (v_mfma_f32_16x16x4_f32: an fp32 FMA chain).  Grid (volumes, K slices),
-// wave = (m-tile of 16 jb, n-tile of 16 o): rows 15jb .. 15jb+14 of R are contiguous, so the A operand of output row jb is
-// simply R_v[1920 jb + k].  The slices are summed in a fixed order by delta_prepare_kernel.
+// A2raw[v][ksl][jb][o] for right volume v (v = ridx[b] if ridx else 0): grid (volumes, K slices), wave = tile; the task itself is
+// ovn_delta_a2_task (delta_a2.h), which the yaw kernel of small 1-vs-N sweeps runs in extra workgroups of its own launch instead.
 __global__ __launch_bounds__(512) void delta_a2_kernel(const float* __restrict__ feats_r, const int32_t* __restrict__ ridx,
                                                        const float* __restrict__ w1raw, float* __restrict__ a2raw) {
   const int b = blockIdx.x, ksl = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int lrow = lane & 15, g = lane >> 4;
-  const int mt = wave >> 2, nt = wave & 3;
-  constexpr int KS = K1 / 4 / A2_KSPLIT;   // 60 k-steps of 4 per slice
-  static_assert(K1 % (4 * A2_KSPLIT) == 0 && KS % 4 == 0, "K slices must be whole groups of 4 k-steps");
   const float* R = feats_r + (long long)(ridx ? ridx[b] : 0) * OVN_FEAT_ELEMS;
-  const int jb = 16 * mt + lrow;
-  // K order inside a slice: step (j, e) takes k = 16 j + 4 g + e from lane group g -- a lane's four consecutive k are ONE 16-byte load
-  // of its row (the four lane groups of a row read 64 contiguous bytes); k = 4 ks + g, one float per lane and step, made every load
-  // instruction touch 16 rows x 4 bytes at 7.5 KB strides and the kernel address-bound (14 us in front of every sweep).  Any K order
-  // serves as long as A and B agree; chain e sums its 15 steps in order, the chains are combined as before.
-  static_assert(KS % 4 == 0, "a slice is whole groups of 16 k");
-  const float* arow = R + (size_t)(jb < G ? jb : G - 1) * K1 + 4 * KS * ksl + 4 * g;
-  const float* bcol = w1raw + (size_t)(4 * KS * ksl + 4 * g) * O1 + 16 * nt + lrow;
-  f32x4 acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // independent chains
-  f32x4 av[KS / 4];
-  float bv[KS / 4][4];
-#pragma unroll
-  for (int j = 0; j < KS / 4; ++j) {
-    av[j] = *reinterpret_cast<const f32x4*>(arow + 16 * j);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) bv[j][e] = bcol[(size_t)(16 * j + e) * O1];
-  }
-#pragma unroll
-  for (int j = 0; j < KS / 4; ++j) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][e], bv[j][e], acc[e], 0, 0, 0);
-  }
-  const f32x4 s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int row = 16 * mt + 4 * g + r;
-    if (row < G) a2raw[((size_t)b * A2_KSPLIT + ksl) * A2_ELEMS + row * O1 + 16 * nt + lrow] = s[r];
-  }
+  ovn_delta_a2_task(R, w1raw, a2raw + (size_t)b * A2_KSPLIT * A2_ELEMS, ksl * 8 + (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63));
 }
 
 // WsP[ks(4)][nt(4)][hl(2)][lane(64)][e(8)]: sws * Ws[c = 32 ks + 8 (lane>>4) + e][o = 16 nt + (lane&15)], Ws = W1 summed over its taps
@@ -1394,9 +1361,18 @@ static int pick_nsplit(int n) {
 }
 
 // a2 + prepare (profile class delta_prep), c_conv1 contraction (delta_c12), c_conv2 GEMM (delta_c2)
+// where ovn_delta_c12_f16x3_forward keeps A2raw inside its scratch (the yaw launch of a small sweep fills it: a2_done)
+float* ovn_delta_f16x3_a2raw(void* scratch, int n) {
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  char* p = static_cast<char*>(scratch);
+  p += al((size_t)n * 8 * sizeof(float)) + al((size_t)n * sizeof(unsigned)) + 2 * al((size_t)n * OVN_FEAT_ELEMS * sizeof(unsigned)) +
+       al((size_t)n * LIN_ELEMS * sizeof(float));
+  return reinterpret_cast<float*>(p);
+}
+
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream,
-                                int pair0, const float* dcache_l) {
+                                int pair0, const float* dcache_l, bool a2_done) {
   int rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(delta_prepare_split_kernel<false>), PREP_SPLIT_LDS);
   if (rc) return rc;
   if (ridx) dcache_l = nullptr;   // the cache serves the 1-vs-N form (one query against many cached candidates)
@@ -1431,7 +1407,8 @@ int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_
   const int nsplit = pick_nsplit(n);   // 45 / 23: 8-row / one-row-tile passes, one per workgroup, chosen for <= 5 / <= 10 pairs
   {
     OvnProfScope ps(ctx, OVN_K_DELTA_PREP, stream);
-    hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
+    if (!a2_done)
+      hipLaunchKernelGGL(delta_a2_kernel, dim3(ridx ? n : 1, A2_KSPLIT), dim3(512), 0, stream, feats_r, ridx, ctx->w1raw, a2raw);
     if (dcache_l) {   // the query kernel also builds the live-channel list and gathers the W1 fragments for it
       hipLaunchKernelGGL(delta_query_kernel, dim3(live ? QV + QGW : QV), dim3(512), 0, stream, feats_r, a2raw, ctx->w2sum, qblock, live ? live_buf : nullptr,
                          reinterpret_cast<const _Float16*>(ctx->w1p_h), w1c);

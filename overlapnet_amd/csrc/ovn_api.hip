@@ -493,6 +493,7 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   ctx->dbg_n = sub < cmax ? sub : cmax;      // the activations of the first sub-chunk stay addressable for the tests
 
   OvnFork fk(ctx, stream);
+  bool a2_in_yaw = false;
   if (corr_mode == 2) {
     hipStream_t ys = stream;
     if (ctx->head_yaw_side) {
@@ -500,7 +501,10 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
       if (rc) return rc;
     }
     OvnProfScope ps(ctx, OVN_K_CORR_SPECTRAL, ys);
-    rc = ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, ys);
+    // a small 1-vs-N sweep in one sub-chunk: the query's right-volume term of the Delta head rides in the yaw launch (csrc/delta_a2.h)
+    a2_in_yaw = fused && ridx == nullptr && n <= OVN_A2_IN_YAW_MAX_PAIRS && n <= chunk && ys == stream && nsub_max == 1 && ctx->head_s == OVN_S;
+    rc = ovn_corr_spectral_forward(ctx, spec_l, lidx, spec_r, ridx, (int)n, yaw, corr, ys, a2_in_yaw ? feats_r : nullptr,
+                                   a2_in_yaw ? ovn_delta_f16x3_a2raw(dscratch, (int)n) : nullptr);
     if (rc) return rc;
   }
   for (int64_t c0 = 0; c0 < n; c0 += chunk) {
@@ -529,7 +533,7 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
         float* part = o3 + (size_t)q0 * OVN_DENSE_PARTIALS;
         rc = ovn_delta_c12_f16x3_forward(ctx, fl, li, feats_r, ri, np, dscratch + (size_t)j * sc_sub, &o2max, o2s, st, (int)(p0 & 0x3fffffff),
                                           // a cache row belongs to a CANDIDATE: without an index list it moves with the feature pointer
-                                          dcache_l ? (lidx ? dcache_l : dcache_l + (size_t)p0 * OVN_DELTA_CACHE_ELEMS) : nullptr);
+                                          dcache_l ? (lidx ? dcache_l : dcache_l + (size_t)p0 * OVN_DELTA_CACHE_ELEMS) : nullptr, a2_in_yaw);
         if (rc) return rc;
         if (p0 == 0) ctx->dbg_o2max = o2max;
         {

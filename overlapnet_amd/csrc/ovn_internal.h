@@ -69,6 +69,7 @@ constexpr int OVN_C2_OUT = 128;   // c_conv2 filters
 constexpr int OVN_C3_OUT = 256;   // c_conv3 filters
 constexpr int OVN_O3_HW = OVN_G - 2;                 // 22
 constexpr int OVN_DENSE_IN = OVN_O3_HW * OVN_O3_HW * OVN_C3_OUT;  // 123904
+constexpr int OVN_A2_IN_YAW_MAX_PAIRS = 64;                  // sweeps up to this many pairs carry the query's A2 tasks in their yaw launch
 constexpr int OVN_DENSE_PARTIALS = 12;                        // Dense partial sums per pair left by c3_dense_kernel: 3 row bands x 2 channel halves x 2 m-tile halves
 constexpr int OVN_ACTMAX_SLOTS = 32;                           // layers with per-scan activation maxima (f16x3 scales)
 constexpr int OVN_LEG_SLICE = 1024;                             // scans per pass of ovn_leg over its ping-pong scratch
@@ -257,7 +258,9 @@ size_t ovn_delta_f16x3_scratch_bytes(int n, bool per_pair_right);
 int ovn_delta_c12_f16x3_forward(ovn_ctx* ctx, const float* feats_l, const int32_t* lidx, const float* feats_r,
                                 const int32_t* ridx, int n, void* scratch, unsigned** o2max_out, float* o2, hipStream_t stream,
                                 int pair0 = 0,    // pair0: index of the call's first pair in the sweep (rotation of the K walks)
-                                const float* dcache_l = nullptr);   // Delta cache rows of the left pool (ovn_delta_cache), 1-vs-N only
+                                const float* dcache_l = nullptr,   // Delta cache rows of the left pool (ovn_delta_cache), 1-vs-N only
+                                bool a2_done = false);   // A2raw of the (single) right volume is already in the scratch (ovn_delta_f16x3_a2raw)
+float* ovn_delta_f16x3_a2raw(void* scratch, int n);
 int ovn_delta_cache_forward(ovn_ctx* ctx, const float* feats, int n, float* cache, hipStream_t stream);
 int ovn_delta_walk_stats(ovn_ctx* ctx, int32_t* out16, hipStream_t stream);
 
@@ -301,8 +304,10 @@ int ovn_gt_range_forward(const float* points, const int64_t* offsets, int n_scan
 int ovn_gt_count_forward(const float* ref_ranges, const float* cur_range, int n, int npix, int32_t* counts, hipStream_t stream);
 int ovn_best_match_forward(const float* overlap, const int32_t* yaw, const int32_t* ids, int n, float threshold,
                            int index_offset, int32_t* out, hipStream_t stream);
+// a2_feats_r / a2raw non-NULL (small 1-vs-N sweeps): the launch also computes A2raw of that right volume (delta_a2.h) in extra workgroups
 int ovn_corr_spectral_forward(ovn_ctx* ctx, const float* spec_l, const int32_t* lidx, const float* spec_r,
-                              const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream);
+                              const int32_t* ridx, int n, int32_t* yaw, float* corr, hipStream_t stream,
+                              const float* a2_feats_r = nullptr, float* a2raw = nullptr);
 
 // projection.hip
 int ovn_project_forward(ovn_ctx* ctx, const float* points, const int64_t* offsets, int n_scans,
