@@ -171,8 +171,9 @@ int ovn_get_head_pipeline(ovn_ctx* ctx, int64_t* chunk_pairs, int64_t* sub_chunk
  * `if np.max(overlaps) > overlap_thres: return reference_idx[np.argmax(overlaps)]`; first maximum wins, NaN never wins).
  *   overlap_dev (n) f32, yaw_dev (n) i32 or NULL: outputs of ovn_heads / ovn_delta_head (+ ovn_corr_head_spectral)
  *   ids_dev     (n) i32 candidate ids (reference_idx) or NULL -> position + index_offset (the shard's first candidate)
- *   out_dev     4 x int32: { id of the best candidate (-1 when n == 0), float bits of its overlap, its yaw,
- *                            1 if overlap > threshold else 0 }
+ *   out_dev     4 x int32, 16-byte aligned: { id of the best candidate (-1 when n == 0), float bits of its overlap, its yaw,
+ *                            1 if overlap > threshold else 0 } -- written with ONE 16-byte store; it may be pinned host memory
+ *                            (device-visible at the same address): the host then needs no device-to-host copy and may poll word 3
  * Ranks of a sharded sweep exchange these 16-byte records instead of N scores (overlapnet_amd/distributed.py). */
 int ovn_best_match(ovn_ctx* ctx, const float* overlap_dev, const int32_t* yaw_dev, const int32_t* ids_dev, int64_t n,
                    float threshold, int64_t index_offset, int32_t* out_dev, void* stream);

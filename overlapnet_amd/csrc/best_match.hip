@@ -50,17 +50,12 @@ __global__ __launch_bounds__(BM_THREADS) void best_match_kernel(const float* __r
   __syncthreads();
   if (threadIdx.x == 0) {
     for (int w = 1; w < BM_THREADS / 64; ++w) b = better(b, Best{sv[w], sk[w]});
-    if (b.k < 0) {
-      out[0] = -1;
-      out[1] = 0;
-      out[2] = 0;
-      out[3] = 0;
-    } else {
-      out[0] = ids ? ids[b.k] : b.k + index_offset;
-      out[1] = __float_as_int(b.v);
-      out[2] = yaw ? yaw[b.k] : 0;
-      out[3] = b.v > threshold ? 1 : 0;
-    }
+    // ONE 16-byte store: a host that polls word 3 of a record in pinned host memory (engine.best_match(host=True)) sees the four
+    // words appear together
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 rec = {-1, 0, 0, 0};
+    if (b.k >= 0) rec = (i32x4){ids ? ids[b.k] : b.k + index_offset, __float_as_int(b.v), yaw ? yaw[b.k] : 0, b.v > threshold ? 1 : 0};
+    *reinterpret_cast<i32x4*>(out) = rec;
   }
 }
 

@@ -19,6 +19,9 @@ FEAT_W = 360
 FEAT_C = 128
 
 
+_MATCH_PENDING = 0x7FFFFFF0      # word 3 of a best-match record that the kernel has not written yet (it writes 0 or 1)
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -329,15 +332,24 @@ class OvnEngine:
         if host:
             if getattr(self, "_match_host", None) is None:
                 self._match_host = torch.empty(4, dtype=torch.int32).pin_memory()
-            out = self._match_host
+                self._match_host_np = self._match_host.numpy()          # the same memory
+            out, view = self._match_host, self._match_host_np
+            view[3] = _MATCH_PENDING                                      # the kernel's one 16-byte store replaces it (0 or 1)
         else:
             out = torch.empty(4, dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.ovn_best_match(self._h, _ptr(overlap), _ptr(yaw), _ptr(ids), n, float(threshold),
                                                int(index_offset), _ptr(out), self._stream()), "ovn_best_match")
             if host:
-                torch.cuda.current_stream(self.device).synchronize()
-                return out.clone()
+                # poll the record instead of waiting for the stream: the wake-up of a stream wait costs more than the kernel
+                spins = 0
+                while view[3] == _MATCH_PENDING:
+                    spins += 1
+                    if spins > 200000:                                    # (~20 ms) something is wrong: let the stream say what
+                        torch.cuda.current_stream(self.device).synchronize()
+                        if view[3] == _MATCH_PENDING:
+                            raise _lib.OvnError("best_match(host=True): the decision record never arrived")
+                return torch.from_numpy(view.copy())
         return out
 
     # -- preprocessing ------------------------------------------------------------------------------
