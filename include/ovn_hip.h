@@ -267,7 +267,8 @@ int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3
  * below), [1] channels of the query that are non-zero somewhere in its 360 columns, [2..13] slices the live channels of column-group
  * pairs 0..11 need (a pair = two column groups of c_conv1, generateNet.py:96-100; a wave skips a slice none of its column groups
  * walks), [14] 1 if the dead-channel compaction applied (ovn_set_head_compaction), else 0 and every entry says 4 slices / 128
- * channels.  Synchronises `stream`.  bench.py reports roofline.k_walk_frac from it. */
+ * channels, [15] MFMA steps of the LAST slice when it is packed tap-major (it then holds <= 16 live channels: 3, 6 or 9 steps instead
+ * of 15; 0 = not packed).  Synchronises `stream`.  bench.py reports roofline.k_walk_frac from it. */
 int ovn_head_walk_stats(ovn_ctx* ctx, int32_t* out16_host, void* stream);
 
 /* Device scratch currently held by the context, in bytes (grows on demand, freed by ovn_destroy). */

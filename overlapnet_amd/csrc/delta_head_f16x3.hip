@@ -94,6 +94,30 @@ __device__ __forceinline__ u32x4 pack4(const f32x4& v, float sa, float csa) {
   return w;
 }
 
+// R words of the PACKED last slice of a compacted walk (TailPack, below) for all 24 column groups: item = (column group jb, step u,
+// lane group gq) -> 8 words [jb][slice][u][gq][0..7], entry k = 8 gq + e = tap (u T + k / n) of channel chan[32 slice + k]; pad
+// entries are zero words.  512 threads.
+struct TailPack;
+__device__ __forceinline__ int tail_tap(const TailPack& t, int u, int k);
+template <class TP>
+__device__ __forceinline__ void pack_tail_slice(const float* __restrict__ Rf, const unsigned char* chan, const TP& tp, unsigned* __restrict__ Pr,
+                                                float sa, float csa, int tid) {
+  const int items = OVN_G * tp.steps * 4;
+  for (int it = tid; it < items; it += 512) {
+    const int gq = it & 3, u = (it >> 2) % tp.steps, jb = (it >> 2) / tp.steps;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int tap = tail_tap(tp, u, 8 * gq + e);
+      const float v = Rf[(size_t)(OVN_S * jb + (tap < 0 ? 0 : tap)) * OVN_FEAT_C + chan[32 * tp.sl + 8 * gq + e]];
+      x[e] = tap < 0 ? 0.0f : v;        // a pad entry packs to the zero word (a packed slice exists only without a shift: csa = 0)
+    }
+    unsigned* dst = Pr + ((jb * 4 + tp.sl) * OVN_S + u) * 32 + gq * 8;
+    *reinterpret_cast<u32x4*>(dst) = pack4((f32x4){x[0], x[1], x[2], x[3]}, sa, csa);
+    *reinterpret_cast<u32x4*>(dst + 4) = pack4((f32x4){x[4], x[5], x[6], x[7]}, sa, csa);
+  }
+}
+
 // (x0, x1), already scaled -> packed fp16 hi pair (rtz) and lo pair (rne of the exact remainder; `one` = 1.0f in a register keeps
 // the fma from being folded into a subtraction that needs two more conversions)
 __device__ __forceinline__ void split_pair(float x0, float x1, float one, unsigned& hi_pk, unsigned& lo_pk) {
@@ -277,7 +301,30 @@ constexpr size_t QBLOCK_WORDS = (size_t)QV * OVN_FEAT_ELEMS + G * O2 + 4;
 constexpr int NPAIR = G / 2;               // column-group pairs (the passes of the contraction kernel)
 constexpr int LIVE_WORDS = 4 + FC / 4 + 4; // {largest slice count, live channels, 0, 0} | 128 channel bytes: position 32 s + 8 g + e of the
                                            // compacted walk | slices to walk for column groups 2 p, 2 p + 1 (12 bytes, + 4 of padding)
-constexpr int CHAN_BYTES = FC + 16;        // the table in LDS: channel bytes + per-pair slice counts
+constexpr int CHAN_BYTES = FC + 16;        // the table in LDS: channel bytes + per-pair slice counts + the packed last slice (below)
+// The LAST slice of a compacted walk, when it holds n <= 16 live channels, is packed TAP-MAJOR: a step then carries T = 32 / n taps of
+// those n channels (entry k of step u = tap u T + k / n of channel k % n) and the slice has ceil(15 / T) steps (rounded up to whole
+// chunks of 3) instead of 15 -- a query with 99 live channels walks 3 x 15 + 3 steps, not 4 x 15.  Table bytes FC + 12 .. FC + 15:
+// {steps of the packed slice (15: nothing is packed), its index (255: none), T, n}; the table's 32 positions of that slice are
+// written in ENTRY order (channel of entry k), so the L slice the contraction kernel fetches by the table already is the A operand's
+// order and the kernel itself only needs the step count.  Pad entries (k >= T n, tap >= 15) carry zero R words and zero weights.
+constexpr int TB_STEPS = FC + 12, TB_SLICE = FC + 13, TB_T = FC + 14, TB_N = FC + 15;
+struct TailPack {
+  int sl, steps, T, n;   // sl < 0: no packed slice
+};
+__device__ __forceinline__ TailPack tail_of(const unsigned char* chan) {
+  TailPack t;
+  t.sl = chan[TB_SLICE] == 255 ? -1 : (int)chan[TB_SLICE];
+  t.steps = chan[TB_STEPS];
+  t.T = chan[TB_T];
+  t.n = chan[TB_N];
+  return t;
+}
+// tap of entry k of step u of the packed slice, or -1 for a pad entry
+__device__ __forceinline__ int tail_tap(const TailPack& t, int u, int k) {
+  const int tap = u * t.T + k / t.n;
+  return (k < t.T * t.n && tap < S) ? tap : -1;
+}
 __device__ __forceinline__ int ident_chan(int pos) { return 32 * ((pos >> 3) & 3) + 8 * (pos >> 5) + (pos & 7); }
 __device__ __forceinline__ unsigned ident_chan_word(int w) {
   return (unsigned)ident_chan(4 * w) | (unsigned)ident_chan(4 * w + 1) << 8 | (unsigned)ident_chan(4 * w + 2) << 16 | (unsigned)ident_chan(4 * w + 3) << 24;
@@ -285,7 +332,8 @@ __device__ __forceinline__ unsigned ident_chan_word(int w) {
 // channel table of a workgroup -> LDS (`use`: workgroup-uniform); returns the number of slices.  Caller synchronises.
 __device__ __forceinline__ int load_chan_table(const unsigned* __restrict__ live, bool use, unsigned char* chan_s, int tid) {
   if (tid < FC / 4) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : ident_chan_word(tid);
-  else if (tid < FC / 4 + 4) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : 0x04040404u;
+  else if (tid < FC / 4 + 3) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : 0x04040404u;
+  else if (tid == FC / 4 + 3) reinterpret_cast<unsigned*>(chan_s)[tid] = use ? live[4 + tid] : (15u | 255u << 8 | 1u << 16 | 32u << 24);
   return use ? (int)live[0] : 4;
 }
 
@@ -296,7 +344,7 @@ __device__ __forceinline__ int load_chan_table(const unsigned* __restrict__ live
 // a column-group pair whose own live channels fit fewer slices than the query's walks fewer (the benchmark's query: 94 live channels,
 // 3 slices everywhere; under the trained-like weights 99 live -> 4 slices as a whole, but 3 in ten of its twelve pairs).
 // Every thread of the (512-thread) workgroup must call it.  `scr`: 2 FC + 32 ints of LDS.
-// Leaves chan_s[0 .. 127] and chan_s[FC + p]; returns the number of live channels.
+// Leaves chan_s[0 .. 127], chan_s[FC + p] and the packed-slice bytes; returns the number of live channels.
 __device__ __forceinline__ int build_chan_list(const int (*alive2)[FC], bool shifted, unsigned char* chan_s, int* scr, int tid) {
   int* cnt_s = scr;            // [FC] pairs position q is alive in
   int* nmax = scr + FC;        // [2 waves][16]: walk length of pair p = 0 .. 11; [12] live channels
@@ -346,11 +394,29 @@ __device__ __forceinline__ int build_chan_list(const int (*alive2)[FC], bool shi
     }
   }
   __syncthreads();
+  const int nlive = nmax[NPAIR] + nmax[16 + NPAIR];
+  // the packed last slice (TailPack above): live channels hold ranks 0 .. nlive - 1
+  const int nsl = nlive > 0 ? (nlive + 31) / 32 : 1;
+  const int n_last = nlive - 32 * (nsl - 1);
+  int t_steps = S, t_T = 1;
+  if (!shifted && nlive > 0 && n_last <= 16) {
+    t_T = 32 / n_last;
+    t_steps = 3 * (((S + t_T - 1) / t_T + 2) / 3);
+  }
+  const bool packed = t_steps < S;
   if (tid < 16) {
     int ns = tid < NPAIR ? (max(nmax[tid], nmax[16 + tid]) + 31) / 32 : 0;
-    chan_s[FC + tid] = (unsigned char)(tid < NPAIR ? (ns < 1 ? 1 : ns) : 4);
+    unsigned char v = (unsigned char)(tid < NPAIR ? (ns < 1 ? 1 : ns) : 4);
+    if (tid == TB_STEPS - FC) v = (unsigned char)t_steps;
+    if (tid == TB_SLICE - FC) v = (unsigned char)(packed ? nsl - 1 : 255);
+    if (tid == TB_T - FC) v = (unsigned char)t_T;
+    if (tid == TB_N - FC) v = (unsigned char)(packed ? n_last : 32);
+    chan_s[FC + tid] = v;
   }
-  const int nlive = nmax[NPAIR] + nmax[16 + NPAIR];
+  if (packed && tid >= 64 && tid < 96) {   // entry order: position k of the slice <- the channel of entry k (k % n)
+    const int k = tid - 64;
+    if (k >= n_last) chan_s[32 * (nsl - 1) + k] = chan_s[32 * (nsl - 1) + k % n_last];
+  }
   __syncthreads();
   return nlive;
 }
@@ -392,12 +458,15 @@ __device__ __forceinline__ void w1c_gather8(const _Float16* __restrict__ w1p, co
   const int step = idx8 >> 9;                   // sc * 15 + dj
   const int sc = step / S, dj = step - sc * S;
   const unsigned char* cp = chan + 32 * sc + 8 * (lane >> 4);
+  const TailPack tp = tail_of(chan);
   f16x8 v;
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     const int ch = cp[e];
-    const int src_step = ((ch & 31) >> 3) * S + dj;
-    v[e] = w1p[((((size_t)src_step * 4 + nt) * 2 + hl) * 64 + (lane & 15) + 16 * (ch >> 5)) * 8 + (ch & 7)];
+    const int tap = (sc == tp.sl) ? tail_tap(tp, dj, 8 * (lane >> 4) + e) : dj;   // packed slice: `dj` is its step
+    const int src_step = ((ch & 31) >> 3) * S + (tap < 0 ? 0 : tap);
+    const _Float16 w = w1p[((((size_t)src_step * 4 + nt) * 2 + hl) * 64 + (lane & 15) + 16 * (ch >> 5)) * 8 + (ch & 7)];
+    v[e] = tap < 0 ? (_Float16)0.0f : w;
   }
   *reinterpret_cast<f16x8*>(w1c + (size_t)idx8 * 8) = v;
 }
@@ -611,12 +680,14 @@ __global__ __launch_bounds__(512) void delta_prepare_split_kernel(
     const int ns = load_chan_table(live, compact, chan_p, tid);
     __syncthreads();
     unsigned* Pr = pr + (size_t)pair * OVN_FEAT_ELEMS;
+    const TailPack tp = tail_of(chan_p);
+    if (tp.sl >= 0) pack_tail_slice(Rf, chan_p, tp, Pr, sa, csa, tid);
 #pragma unroll 2
     for (int k = 0; k < 12; ++k) {
       const int i8 = tid + 512 * k;
       if (i8 < R_ITEMS) {
         const int jrow = i8 >> 4, sc = (i8 >> 2) & 3, gq = i8 & 3;
-        if (sc < ns) {
+        if (sc < ns && sc != tp.sl) {
           const int jb = jrow / S, dj = jrow - jb * S;
           const float* rrow = Rf + (size_t)jrow * FC;
           const unsigned char* ch = chan_p + 32 * sc + 8 * gq;
@@ -872,12 +943,13 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
       gv[k][0] = (f32x4){rrow[ch[0]], rrow[ch[1]], rrow[ch[2]], rrow[ch[3]]};
       gv[k][1] = (f32x4){rrow[ch[4]], rrow[ch[5]], rrow[ch[6]], rrow[ch[7]]};
     }
+    const TailPack tp = tail_of(chan_q);
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
       const int i8 = tid + 512 * k;
       if (i8 < R_ITEMS) {
         const int jrow = i8 >> 4, sc = (i8 >> 2) & 3, gq = i8 & 3;
-        if (sc < ns) {
+        if (sc < ns && sc != tp.sl) {
           const int jb = jrow / S, dj = jrow - jb * S;
           unsigned* dst = Pr + ((jb * 4 + sc) * S + dj) * 32 + gq * 8;
           *reinterpret_cast<u32x4*>(dst) = pack4(gv[k][0], sa, 0.0f);
@@ -885,6 +957,8 @@ __global__ __launch_bounds__(512) void delta_query_kernel(const float* __restric
         }
       }
     }
+    // the packed last slice (TailPack): step u of column group jb holds the taps u T .. u T + T - 1 of its n channels
+    if (tp.sl >= 0) pack_tail_slice(feats_r, chan_q, tp, Pr, sa, 0.0f, tid);
   }
   // AA and {max, min} are left by the LAST workgroup of the launch (a gather helper when the sweep compacts): workgroup 0's packing and
   // this dot product run side by side instead of one after the other
@@ -967,7 +1041,7 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
   constexpr int PFN = T_CHB / (512 * 16);        // W1 DMA instructions per lane and chunk
   constexpr int RPJ = T_SPC * 8;                 // 16-byte pieces of an R chunk per column group
   constexpr int RFN = (G * RPJ + 511) / 512;     // R DMA instructions per lane and chunk (the last one partial, whole waves)
-  static_assert(S % T_SPC == 0 && T_CHB % (512 * 16) == 0 && T_CPS >= 2 && (G * RPJ) % 64 == 0, "bad chunking");
+  static_assert(S % T_SPC == 0 && T_CHB % (512 * 16) == 0 && T_SPC == 3 && (G * RPJ) % 64 == 0, "bad chunking (the packed slice has 3, 6 or 9 steps)");
   __shared__ __attribute__((aligned(16))) unsigned char chan_s[CHAN_BYTES];
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* wst = smem_raw;                                                   // [2][T_CHB]
@@ -999,6 +1073,9 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
 #pragma unroll
   for (int j = 0; j < 3; ++j) ns_full[j] = __builtin_amdgcn_readfirstlane((int)chan_s[FC + ((3 * wave + j) >> 1)]);
   // short pass: waves 0 .. 3 take two tiles (column groups 4 w .. 4 w + 3), waves 4 .. 7 one (16 + 2 (w - 4), + 1): three per SIMD
+  // chunks of a slice: 5, or fewer for the packed last slice of a compacted walk (TailPack: 3, 6 or 9 steps)
+  const int pk_sl = __builtin_amdgcn_readfirstlane(chan_s[TB_SLICE] == 255 ? -1 : (int)chan_s[TB_SLICE]);
+  const int pk_cps = __builtin_amdgcn_readfirstlane((int)chan_s[TB_STEPS] / T_SPC);
   const int tail_jb0 = __builtin_amdgcn_readfirstlane(wave < 4 ? 4 * wave : 16 + 2 * (wave - 4));
   const int tail_slots = __builtin_amdgcn_readfirstlane(wave < 4 ? 2 : 1);
 #pragma unroll
@@ -1084,14 +1161,15 @@ __global__ __launch_bounds__(512) void delta_c1_f16x3_kernel(const DeltaDesc* __
       // A slice beyond a column group's own walk adds exact zeros to it (its channels there are dead in the query's columns of that
       // group), so skipping is only ever an optimisation: a wave skips the MFMAs of a slice when NONE of its slots walks it -- one
       // wave-uniform test per chunk; a test per slot would end the scheduling region at every slot
+      const int cps = (sl == pk_sl) ? pk_cps : T_CPS;
 #pragma unroll 1
-      for (int c5 = 0; c5 < T_CPS; ++c5) {
+      for (int c5 = 0; c5 < cps; ++c5) {
         {   // the next chunk of the walk (the first one of the next pass after the last): W1 fragments + R words, one chunk ahead
-          const int sl_x = (c5 + 1 < T_CPS) ? sl : sl_n, c5_x = (c5 + 1 < T_CPS) ? c5 + 1 : 0;
+          const int sl_x = (c5 + 1 < cps) ? sl : sl_n, c5_x = (c5 + 1 < cps) ? c5 + 1 : 0;
           OVN_DMA_W(T_CPS * sl_x + c5_x, cur ^ 1)
           OVN_DMA_R(sl_x, c5_x, cur ^ 1)
         }
-        if (c5 == 1) {   // the next L slice: of this pass, or the first of the next pass
+        if (c5 == 0) {   // the next L slice (into the other buffer): of this pass, or the first of the next pass
           if (!last_slice) {
             OVN_DMA_L(sl_n, row0, TAIL ? 8 : 16 * RT, lcur ^ 1)
           } else if (has_next) {
@@ -1471,6 +1549,7 @@ int ovn_delta_walk_stats(ovn_ctx* ctx, int32_t* out16, hipStream_t stream) {
   const unsigned char* nsp = reinterpret_cast<const unsigned char*>(h + 4) + FC;
   for (int p = 0; p < NPAIR; ++p) out16[2 + p] = nsp[p];
   out16[14] = 1;
+  out16[15] = nsp[TB_STEPS - FC] < S ? (int32_t)nsp[TB_STEPS - FC] : 0;   // steps of the packed last slice (0: none)
   return OVN_OK;
 }
 

@@ -468,13 +468,19 @@ class OvnEngine:
         """The K walk the Delta head's contraction took in the most recent 1-vs-N sweep (`ovn_head_walk_stats`): per column-group pair
         the slices of 32 channels its live channels need (`slices_per_group_pair`, 12 entries), the query's live channels, and
         `k_walk_frac` = the MFMAs the kernel issued / those of the 128-channel walk: wave w of the contraction kernel holds column
-        groups 3 w .. 3 w + 2 and skips a slice when none of them walks it (csrc/delta_head_f16x3.hip)."""
+        groups 3 w .. 3 w + 2 and skips a slice when none of them walks it; a last slice of <= 16 live channels is packed tap-major
+        into `packed_last_slice_steps` steps instead of 15 (csrc/delta_head_f16x3.hip)."""
         out = (C.c_int32 * 16)()
         _lib.check(self.lib.ovn_head_walk_stats(self._h, out, self._stream()), "ovn_head_walk_stats")
         spp = [int(out[2 + p]) for p in range(12)]
         per_wave = [max(spp[(3 * w) // 2], spp[(3 * w + 2) // 2]) for w in range(8)]
-        return {"max_slices": int(out[0]), "live_channels": int(out[1]), "slices_per_group_pair": spp,
-                "compacted": bool(out[14]), "k_walk_frac": sum(per_wave) / 32.0, "k_walk_frac_time": int(out[0]) / 4.0}
+        nsm, tail = int(out[0]), int(out[15])
+
+        def steps(ns):      # MFMA steps of a walk of ns slices: 15 each, the packed last slice (if it is among them) `tail`
+            return 15 * ns - ((15 - tail) if (tail and ns == nsm) else 0)
+        return {"max_slices": nsm, "live_channels": int(out[1]), "slices_per_group_pair": spp, "packed_last_slice_steps": tail,
+                "compacted": bool(out[14]), "k_walk_frac": sum(steps(n) for n in per_wave) / (8 * 60.0),
+                "k_walk_frac_time": steps(nsm) / 60.0}
 
     def set_projection_trig(self, mode: str) -> None:
         """Which float32 `np.arctan2` / `np.arcsin` (utils.py:86-87) `project` reproduces: 'numpy_avx512' (default: NumPy >= 1.22 on an

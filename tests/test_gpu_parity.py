@@ -1109,7 +1109,9 @@ def test_dead_channel_compaction_of_the_query(engines):
         finally:
             e.set_head_compaction(True)
 
-    for dead in (0, 5, 33, 70, 127, 128):
+    # live = 128 - dead; a last slice of <= 16 live channels is packed tap-major (3, 6 or 9 MFMA steps instead of 15): dead = 28, 61, 93
+    # (4, 3, 3 channels in the last of 4 / 3 / 2 slices), 112, 120, 122, 127 (16, 8, 6, 1 channels in the only slice)
+    for dead in (0, 5, 28, 33, 61, 70, 93, 112, 120, 122, 127, 128):
         q = np.maximum(rng.normal(0.2, 1.0, size=(1, 360, 128)), 0).astype(np.float32)
         kill = rng.permutation(128)[:dead]
         q[:, :, kill] = 0
@@ -1125,7 +1127,15 @@ def test_dead_channel_compaction_of_the_query(engines):
         allf = torch.cat([dc, torch.from_numpy(q).cuda()])
         ri = e.heads(allf, allf, lidx=np.arange(n), ridx=np.full(n, n, np.int64), want_logit=True)["logit"].cpu().numpy()
         assert np.array_equal(ri, lg0)                                                # indexed pairs never compact
-        if dead in (33, 128):
+        st = None
+        if dead not in (0, 128):
+            sweep(q, True)
+            st = e.head_walk_stats()
+            live = 128 - dead
+            n_last = live - 32 * ((live + 31) // 32 - 1)
+            want_steps = 0 if n_last > 16 else 3 * (-(-(-(-15 // (32 // n_last))) // 3))
+            assert st["compacted"] and st["live_channels"] == live and st["packed_last_slice_steps"] == want_steps, (dead, st)
+        if dead in (28, 33, 61, 93, 112, 120, 122, 127, 128):
             fv = cands[:8].reshape(8, 1, 360, 128).astype(np.float64)
             o_ov, o_yaw, o_lg, _ = O.heads_forward(fv, np.repeat(q.reshape(1, 1, 360, 128).astype(np.float64), 8, axis=0), w)
             assert np.max(np.abs(ov1[:8] - o_ov)) <= 1e-4 and np.max(np.abs(lg1[:8] - o_lg)) <= 1e-3 * (1 + np.max(np.abs(o_lg)))
@@ -1167,7 +1177,9 @@ def test_dead_channel_compaction_of_the_query(engines):
             sweep(q, True)
             st = e.head_walk_stats()          # the walk the kernel really took (ovn_head_walk_stats)
             assert st["compacted"] and st["slices_per_group_pair"] == [1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4] and st["live_channels"] == 110, st
-            assert st["max_slices"] == 4 and abs(st["k_walk_frac"] - (1 + 1 + 2 + 2 + 3 + 3 + 4 + 4) / 32.0) < 1e-9, st
+            # the 14 channels of the fourth slice are packed two taps per step: 9 steps instead of 15 for the waves that walk it
+            assert st["max_slices"] == 4 and st["packed_last_slice_steps"] == 9, st
+            assert abs(st["k_walk_frac"] - (15 + 15 + 30 + 30 + 45 + 45 + 54 + 54) / 480.0) < 1e-9, st
         # a sweep of 3 candidates (half-pass workgroups) has the bits of the big one
         e.set_head_compaction(True)
         dq = torch.from_numpy(q).cuda()
