@@ -947,8 +947,9 @@ def test_100k_candidate_sweep_properties(engines):
 
 
 def test_small_sweeps_have_the_bits_of_the_big_sweep(engines):
-    """The Delta kernels pick their workgroup decomposition by sweep size (1 ... 24 workgroups per pair; 24 = one column group each,
-    for the single-pair latency of demo2 / gated demo3 queries): a candidate's result must not depend on it -- every prefix of a
+    """The head kernels pick their workgroup decomposition by sweep size (contraction: 1 ... 45 workgroups per pair; c_conv3 + Dense 3 or 12
+    per pair; small sweeps carry the query's A2 tasks in their yaw launch -- all for the single-pair latency of demo2 / gated demo3
+    queries): a candidate's result must not depend on it -- every prefix of a
     300-candidate sweep has the bits of the full sweep, with and without the Delta cache, with and without an index list."""
     e = engines[4]
     rng = np.random.default_rng(8)
@@ -957,7 +958,9 @@ def test_small_sweeps_have_the_bits_of_the_big_sweep(engines):
     q = fv[7:8].contiguous()
     spec, qs, dc = e.spectrum(fv), e.spectrum(fv[7:8].contiguous()), e.delta_cache(fv)
     full = e.heads(fv, q, spec_l=spec, spec_r=qs, want_logit=True, dcache_l=dc)
-    for n in (1, 2, 3, 10, 11, 21, 28, 29, 42, 43, 86, 129):      # (either side of every size at which a kernel changes its decomposition)
+    # either side of every size at which a kernel changes its decomposition: contraction 5 | 6 (8-row passes) and 10 | 11 (one row tile
+    # per pass), c_conv3 + Dense 21 | 22 (four workgroups per band), c_conv2 28 | 29, the query's A2 tasks in the yaw launch 64 | 65
+    for n in (1, 2, 3, 5, 6, 10, 11, 21, 22, 28, 29, 42, 43, 64, 65, 86, 129):
         for kw in ({}, {"dcache_l": dc[:n].contiguous()}):
             r = e.heads(fv[:n].contiguous(), q, spec_l=spec[:n].contiguous(), spec_r=qs, want_logit=True, **kw)
             assert torch.equal(r["logit"], full["logit"][:n]) and torch.equal(r["yaw"], full["yaw"][:n]), (n, bool(kw))
