@@ -9,7 +9,8 @@
 // in the 36-step K loop (9 taps x 4 channel chunks of 32).  The 8 waves split the 256 output channels (2 n-tiles each), every
 // wave walks all m-tiles (8 x 22 = 176 pixels = 11 exact tiles), 66 MFMAs per K step against 4 weight-fragment loads straight
 // from L2 (prefetched one step ahead).  The Dense dot product is taken in the epilogue on the accumulators (o3 never goes to
-// HBM unless asked for): per-band partial sums, combined in a fixed order by dense_finish_kernel (deterministic).
+// HBM unless asked for): partial sums per (band, channel half, m-tile half), combined in one fixed order by the pair's last
+// workgroup to arrive (deterministic whichever that is).
 #include "ovn_internal.h"
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -50,13 +51,15 @@ __device__ __forceinline__ int band_rows(int b) { return b == 0 ? 8 : 7; }
 // per band -- half of the output channels x tiles 0 .. 5 / 6 .. 10, each with its own copy of the patch, one wave per SIMD: a handful
 // of pairs are a few workgroups per pair deep in their own MFMA time; one workgroup per band 49 us for a single pair, two 37 us, four
 // 23 us).  The Dense partial sums leave the kernel per (band, channel half, m-tile half) in both builds -- the sweep build keeps two
-// sums per thread, split at tile MT_SPLIT -- and are combined in one fixed order by dense_finish_kernel: same bits.
+// sums per thread, split at tile MT_SPLIT -- and are combined in one fixed order by the pair's last workgroup: same bits.
 constexpr int MT_SPLIT = 6;
 template <class A, int NWV, int MSPLIT>
 __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restrict__ o2, const typename A::elem* __restrict__ wp,
                                                            const float* __restrict__ b3, const float* __restrict__ wd,
                                                            const unsigned* __restrict__ o2max, float sw3,
-                                                           float* __restrict__ partial, float* __restrict__ o3) {
+                                                           float* __restrict__ partial, float* __restrict__ o3,
+                                                           unsigned* __restrict__ arrived, const float* __restrict__ bd,
+                                                           float* __restrict__ overlap, float* __restrict__ logit) {
   typedef typename A::elem elem_t;
   typedef typename A::v8 v8_t;
   typedef typename A::v4 v4_t;
@@ -254,51 +257,58 @@ __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restr
     } else {
       dst[2 * half + mh] = (red[0] + red[1]) + (red[2] + red[3]);
     }
-  }
-}
-
-__global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bd, int n,
-                                                           float* __restrict__ overlap, float* __restrict__ logit) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= n) return;
-  const float* q = partial + (size_t)p * OVN_DENSE_PARTIALS;
-  // bands in order; a band = (its two m-tile halves of channel half 0) + (those of channel half 1)
-  float z = 0.f;
+    // Dense bias + sigmoid by the LAST workgroup of the pair to arrive (overlap != NULL): its 12 partial sums are combined in ONE fixed
+    // order whichever workgroup that is -- no separate finishing launch (5 us of a 285 us single-pair query).  `arrived[pair]` counts
+    // the pair's workgroups and is left at zero again; the partials of the other workgroups are read past this CU's caches.
+    if (overlap != nullptr) {
+      constexpr unsigned PARTS = NBAND * HALVES * MSPLIT;
+      __threadfence();
+      const unsigned prev = atomicAdd(arrived + pair, 1u);
+      if (prev == PARTS - 1) {
+        __threadfence();
+        const float* q = partial + (size_t)pair * OVN_DENSE_PARTIALS;
+        float z = 0.f;
 #pragma unroll
-  for (int b = 0; b < NBAND; ++b) {
-    const float zb = (q[4 * b] + q[4 * b + 1]) + (q[4 * b + 2] + q[4 * b + 3]);
-    z = b == 0 ? zb : z + zb;
+        for (int b = 0; b < NBAND; ++b) {
+          const float q0 = __hip_atomic_load(q + 4 * b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float q1 = __hip_atomic_load(q + 4 * b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float q2 = __hip_atomic_load(q + 4 * b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float q3 = __hip_atomic_load(q + 4 * b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float zb = (q0 + q1) + (q2 + q3);     // a band = (its two m-tile halves of channel half 0) + (those of channel half 1)
+          z = b == 0 ? zb : z + zb;                   // bands in order
+        }
+        z += bd[0];
+        if (logit) logit[pair] = z;
+        overlap[pair] = 1.0f / (1.0f + expf(-z));
+        __hip_atomic_store(arrived + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
-  z += bd[0];
-  if (logit) logit[p] = z;
-  overlap[p] = 1.0f / (1.0f + expf(-z));
 }
 
 }  // namespace
 
-// o2 (n,24,24,128) fp32 -> partial (12 n) Dense partial sums per (output-row band, half of the output channels, m-tile half) [+ o3 (n,22,22,256) when not NULL];
-// ovn_dense_finish_forward turns the partials into logit / overlap.
+// o2 (n,24,24,128) fp32 -> Dense partial sums per (output-row band, half of the output channels, m-tile half) in `partial` (12 n) and,
+// with `overlap` given, logit / overlap of every pair (finished by the pair's last workgroup; `arrived`: n zeroed words that the kernel
+// leaves zeroed) [+ o3 (n,22,22,256) when not NULL].
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
-                         hipStream_t stream) {
+                         unsigned* arrived, float* overlap, float* logit, hipStream_t stream) {
   OVN_REQUIRE(o2max != nullptr, OVN_ERR_ARG, "ovn_c3_dense_forward: the per-pair maxima of o2 are required");
+  OVN_REQUIRE(overlap == nullptr || arrived != nullptr, OVN_ERR_ARG, "ovn_c3_dense_forward: arrival counters missing");
   int rc;
   if (n <= 21) {   // a handful of pairs: four 4-wave workgroups per band (12 n <= 252 workgroups: still one round, one per CU)
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, 4, 2>), LDS_BYTES);
     if (rc) return rc;
     hipLaunchKernelGGL((c3_dense_kernel<ArithF16, 4, 2>), dim3(4 * NBAND * n), dim3(64 * 4), LDS_BYTES, stream, o2,
-                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
+                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3, arrived,
+                       ctx->bd, overlap, logit);
   } else {
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, NW, 1>), LDS_BYTES);
     if (rc) return rc;
     hipLaunchKernelGGL((c3_dense_kernel<ArithF16, NW, 1>), dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
-                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3);
+                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3, arrived,
+                       ctx->bd, overlap, logit);
   }
-  OVN_HIP_CHECK(hipGetLastError());
-  return OVN_OK;
-}
-
-int ovn_dense_finish_forward(const ovn_ctx* ctx, const float* partial, int n, float* overlap, float* logit, hipStream_t stream) {
-  hipLaunchKernelGGL(dense_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partial, ctx->bd, n, overlap, logit);
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
 }

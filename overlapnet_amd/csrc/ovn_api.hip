@@ -112,6 +112,7 @@ int ovn_destroy(ovn_ctx* ctx) {
   if (ctx->w2sum) (void)hipFree(ctx->w2sum);
   if (ctx->ws) (void)hipFree(ctx->ws);
   if (ctx->actmax) (void)hipFree(ctx->actmax);
+  if (ctx->c3_arrived) (void)hipFree(ctx->c3_arrived);
   if (ctx->aux_ready) {
     for (int i = 0; i < 2; ++i) {
       (void)hipStreamDestroy(ctx->aux[i]);
@@ -483,6 +484,15 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
   const size_t sc_sub = fused ? al(ovn_delta_f16x3_scratch_bytes((int)sub, ridx != nullptr)) : 0;
   int rc = ovn_ws_reserve(ctx, o2_bytes + o3_bytes + sc_sub * nsub_max, stream);
   if (rc) return rc;
+  if (fused && ctx->c3_arrived_n < chunk) {   // arrival counters of the fused c_conv3 + Dense kernel, one per pair of a chunk (sized
+    OVN_HIP_CHECK(hipStreamSynchronize(stream));   // by the chunk, not by this call: a growing sweep must not re-allocate): zeroed
+    if (ctx->c3_arrived) (void)hipFree(ctx->c3_arrived);   // once, left zeroed by every launch
+    ctx->c3_arrived = nullptr;
+    ctx->c3_arrived_n = 0;
+    OVN_HIP_CHECK(hipMalloc((void**)&ctx->c3_arrived, (size_t)chunk * sizeof(unsigned)));
+    OVN_HIP_CHECK(hipMemsetAsync(ctx->c3_arrived, 0, (size_t)chunk * sizeof(unsigned), stream));
+    ctx->c3_arrived_n = chunk;
+  }
   float* o2 = reinterpret_cast<float*>(ctx->ws);
   float* o3 = reinterpret_cast<float*>(static_cast<char*>(ctx->ws) + o2_bytes);
   char* dscratch = static_cast<char*>(ctx->ws) + o2_bytes + o3_bytes;
@@ -536,13 +546,10 @@ static int delta_head_run(ovn_ctx* ctx, const float* feats_l, const int32_t* lid
                                           dcache_l ? (lidx ? dcache_l : dcache_l + (size_t)p0 * OVN_DELTA_CACHE_ELEMS) : nullptr, a2_in_yaw);
         if (rc) return rc;
         if (p0 == 0) ctx->dbg_o2max = o2max;
-        {
+        {   // c_conv3 + Flatten + Dense + sigmoid: one launch (the pair's last workgroup finishes it)
           OvnProfScope ps(ctx, OVN_K_C3, st);
-          rc = ovn_c3_dense_forward(ctx, o2s, o2max, np, part, nullptr, st);
+          rc = ovn_c3_dense_forward(ctx, o2s, o2max, np, part, nullptr, ctx->c3_arrived + q0, overlap + p0, logit ? logit + p0 : nullptr, st);
         }
-        if (rc) return rc;
-        OvnProfScope ps(ctx, OVN_K_DENSE, st);
-        rc = ovn_dense_finish_forward(ctx, part, np, overlap + p0, logit ? logit + p0 : nullptr, st);
       } else {
         float* o3s = o3 + (size_t)q0 * o3_elems;
         {
@@ -800,7 +807,7 @@ int ovn_debug_head_activations(ovn_ctx* ctx, int64_t n, float* o2_dev, float* o3
     OVN_HIP_CHECK(hipMemcpyAsync(o3_dev, ctx->dbg_o3, (size_t)n * OVN_DENSE_IN * sizeof(float), hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));
   else if (o3_dev)  // f16x3 mode: o3 never left the fused kernel -- run it again on the o2 still in scratch, with o3 output
-    return ovn_c3_dense_forward(ctx, ctx->dbg_o2, ctx->dbg_o2max, (int)n, ctx->dbg_partial, o3_dev, (hipStream_t)stream);
+    return ovn_c3_dense_forward(ctx, ctx->dbg_o2, ctx->dbg_o2max, (int)n, ctx->dbg_partial, o3_dev, nullptr, nullptr, nullptr, (hipStream_t)stream);
   return OVN_OK;
 }
 

@@ -200,6 +200,8 @@ struct ovn_ctx {
   float* dbg_partial = nullptr;
   const unsigned* dbg_o2max = nullptr;
   int64_t dbg_n = 0;
+  unsigned* c3_arrived = nullptr;       // arrival counters of c3_dense_kernel, one per pair of a chunk, zero between launches
+  int64_t c3_arrived_n = 0;
   const unsigned* dbg_live = nullptr;   // live-channel list of the most recent f16x3 Delta sweep (NULL: it walked all 128 channels)
 };
 
@@ -294,8 +296,7 @@ int ovn_leg_tail_forward(const ovn_ctx* ctx, size_t first, const float* in, int 
 // c3_dense.hip: c_conv3 + Flatten + Dense fused (f16x3 mode), input patch resident in LDS
 // o2max: the per-pair maxima of o2 left by the f16x3 Delta kernel (scale of the fp16 split)
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
-                         hipStream_t stream);
-int ovn_dense_finish_forward(const ovn_ctx* ctx, const float* partial, int n, float* overlap, float* logit, hipStream_t stream);
+                         unsigned* arrived, float* overlap, float* logit, hipStream_t stream);
 
 // overlap_gt.hip
 int ovn_gt_range_forward(const float* points, const int64_t* offsets, int n_scans, long long max_points, const double* ref_poses,
