@@ -19,6 +19,15 @@ FEAT_W = 360
 FEAT_C = 128
 
 
+class _NoContext(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_CONTEXT = _NoContext()
 _MATCH_PENDING = 0x7FFFFFF0      # word 3 of a best-match record that the kernel has not written yet (it writes 0 or 1)
 
 
@@ -41,7 +50,7 @@ class OvnEngine:
         self.device = torch.device("cuda", self.device_index)
         self.in_h, self.in_w, self.in_c = int(in_h), int(in_w), int(in_c)
         h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_create(self.device_index, self.in_h, self.in_w, self.in_c, C.byref(h)), "ovn_create")
         self._h = h
         self.feat_w = 0
@@ -57,7 +66,7 @@ class OvnEngine:
     # -- lifetime -----------------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_h", None):
-            with torch.cuda.device(self.device):   # the C side restores the caller's device too; belt and braces
+            with self._dev():   # the C side restores the caller's device too; belt and braces
                 self.lib.ovn_destroy(self._h)
             self._h = None
 
@@ -70,13 +79,19 @@ class OvnEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _dev(self):
+        """Context that makes this engine's GPU torch's current device -- a no-op when it already is (the library selects its context's
+        device itself; what needs the torch side are allocations and streams, and switching costs microseconds per call on the chain
+        of a single query)."""
+        return _NO_CONTEXT if torch.cuda.current_device() == self.device_index else torch.cuda.device(self.device)
+
     # -- weights ------------------------------------------------------------------------------------
     def load_weights(self, weights: Dict[str, np.ndarray], model_cfg: Optional[dict] = None) -> None:
         """Register leg + head weights given by Keras layer name (reference infer.py:117-120)."""
         cfg = model_cfg or {}
         W.check_weights(weights, self.in_c, cfg)
         self.conv1size = int(cfg.get("conv1NetworkHead_conv1size", 15))     # generateNet.py:88-89
-        with torch.cuda.device(self.device):
+        with self._dev():
             st = self._stream()
             for l in W.leg_layers(self.in_c, cfg):
                 k = torch.from_numpy(np.ascontiguousarray(weights[l.name + "/kernel"], np.float32)).to(self.device)
@@ -110,7 +125,7 @@ class OvnEngine:
         n = images.shape[0]
         if out is None:
             out = torch.empty((n, self.feat_w, FEAT_C), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_leg(self._h, _ptr(images), n, _ptr(out), self._stream()), "ovn_leg")
         return out
 
@@ -197,7 +212,7 @@ class OvnEngine:
                     raise _lib.OvnError("dcache_l must hold one Delta cache row per left feature volume")
             yaw = torch.empty(n, dtype=torch.int32, device=self.device)
             corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
-            with torch.cuda.device(self.device):
+            with self._dev():
                 _lib.check(self.lib.ovn_heads_spectral(self._h, _ptr(feats_l), _ptr(spec_l), _ptr(dcache_l), _ptr(li), _ptr(feats_r),
                                                        _ptr(spec_r), _ptr(ri), n, _ptr(overlap), _ptr(yaw), _ptr(logit), _ptr(corr),
                                                        self._stream()), "ovn_heads_spectral")
@@ -209,7 +224,7 @@ class OvnEngine:
             return out
         yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_heads(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n, _ptr(overlap),
                                           _ptr(yaw), _ptr(logit), _ptr(corr), self._stream()), "ovn_heads")
         out = {"overlap": overlap, "yaw": yaw}
@@ -226,7 +241,7 @@ class OvnEngine:
         li, ri, n = self._pairs(feats_l.numel() // (FEAT_W * FEAT_C), feats_r.numel() // (FEAT_W * FEAT_C), lidx, ridx, n)
         yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_corr_head(self._h, _ptr(feats_l), _ptr(li), _ptr(feats_r), _ptr(ri), n, _ptr(yaw),
                                               _ptr(corr), self._stream()), "ovn_corr_head")
         return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
@@ -249,7 +264,7 @@ class OvnEngine:
         n = feats.numel() // (FEAT_W * FEAT_C)
         if out is None:
             out = torch.empty((n, self.DELTA_CACHE_ELEMS), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_delta_cache(self._h, _ptr(feats), n, _ptr(out), self._stream()), "ovn_delta_cache")
         return out
 
@@ -259,7 +274,7 @@ class OvnEngine:
         n = feats.numel() // (FEAT_W * FEAT_C)
         if out is None:
             out = torch.empty((n, FEAT_C, self.SPEC_W), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_spectrum(self._h, _ptr(feats), n, _ptr(out), self._stream()), "ovn_spectrum")
         return out
 
@@ -274,7 +289,7 @@ class OvnEngine:
         li, ri, n = self._pairs(spec_l.numel() // (FEAT_C * self.SPEC_W), spec_r.numel() // (FEAT_C * self.SPEC_W), lidx, ridx, n)
         yaw = torch.empty(n, dtype=torch.int32, device=self.device)
         corr = torch.empty((n, FEAT_W), dtype=torch.float32, device=self.device) if want_corr else None
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_corr_head_spectral(self._h, _ptr(spec_l), _ptr(li), _ptr(spec_r), _ptr(ri), n,
                                                        _ptr(yaw), _ptr(corr), self._stream()), "ovn_corr_head_spectral")
         return {"yaw": yaw, "corr": corr} if want_corr else {"yaw": yaw}
@@ -296,7 +311,7 @@ class OvnEngine:
         if inv_cur_pose is not None and inv_cur_pose.numel() != 16:
             raise _lib.OvnError("inv_cur_pose must be one 4x4 matrix")
         out = torch.empty((n, proj_h, proj_w), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_gt_range_images(self._h, _ptr(points), _ptr(offsets), n, int(max_points), _ptr(ref_poses),
                                                     _ptr(inv_cur_pose), proj_h, proj_w, float(fov_up), float(fov_down),
                                                     float(max_range), _ptr(out), self._stream()), "ovn_gt_range_images")
@@ -311,7 +326,7 @@ class OvnEngine:
         if tuple(cur_range.shape[-2:]) != (h, w) or cur_range.numel() != h * w:
             raise _lib.OvnError("cur_range must be one %dx%d image" % (h, w))
         counts = torch.empty(n + 1, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_gt_overlap_counts(self._h, _ptr(ref_ranges), _ptr(cur_range), n, h, w, _ptr(counts),
                                                       self._stream()), "ovn_gt_overlap_counts")
         return counts
@@ -322,7 +337,8 @@ class OvnEngine:
         """On-device `argmax overlap, > threshold` of demo3 (demo3_lcd.py:117-120).  Returns a 4 x int32 device
         record {candidate id, float bits of overlap, yaw, found}; decode with `decode_match`.  host=True: the kernel writes the
         record straight into pinned host memory (device-visible at the same address) and the call waits for the stream -- the
-        caller reads the decision without a device-to-host copy (one blit kernel and its hand-off less per query)."""
+        caller reads the decision without a device-to-host copy (one blit kernel and its hand-off less per query); the record comes back
+        as a NumPy int32 array."""
         n = int(overlap.numel())
         for t, what, dt in ((overlap, "overlap", torch.float32), (yaw, "yaw", torch.int32), (ids, "ids", torch.int32)):
             if t is None:
@@ -337,7 +353,7 @@ class OvnEngine:
             view[3] = _MATCH_PENDING                                      # the kernel's one 16-byte store replaces it (0 or 1)
         else:
             out = torch.empty(4, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_best_match(self._h, _ptr(overlap), _ptr(yaw), _ptr(ids), n, float(threshold),
                                                int(index_offset), _ptr(out), self._stream()), "ovn_best_match")
             if host:
@@ -349,7 +365,7 @@ class OvnEngine:
                         torch.cuda.current_stream(self.device).synchronize()
                         if view[3] == _MATCH_PENDING:
                             raise _lib.OvnError("best_match(host=True): the decision record never arrived")
-                return torch.from_numpy(view.copy())
+                return view.copy()            # (a NumPy record: `decode_match` takes it as it is)
         return out
 
     # -- preprocessing ------------------------------------------------------------------------------
@@ -387,7 +403,7 @@ class OvnEngine:
                 stk = stacked_out
             else:
                 stk = mk(n, proj_h, proj_w, ud + 3 * un + ui)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_project(self._h, _ptr(points), _ptr(offsets), n, int(max_points), proj_h, proj_w,
                                             float(fov_up), float(fov_down), float(max_range), _ptr(rng), _ptr(vtx),
                                             _ptr(itn), _ptr(idx), _ptr(nrm), _ptr(stk), ud, un, ui, self._stream()),
@@ -406,7 +422,7 @@ class OvnEngine:
         if tuple(vtx.shape) != (n, h, w, 4):
             raise _lib.OvnError("normals(): vertex shape %s does not match range %s" % (tuple(vtx.shape), tuple(rng.shape)))
         out = torch.empty((n, h, w, 3), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_normals(self._h, _ptr(rng), _ptr(vtx), n, h, w, _ptr(out), self._stream()),
                        "ovn_normals")
         return out
@@ -422,7 +438,7 @@ class OvnEngine:
         yaw = torch.empty(n, dtype=torch.float32, device=self.device)
         pitch = torch.empty(n, dtype=torch.float32, device=self.device)
         pix = torch.empty(n, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_projection_angles(self._h, _ptr(points), n, proj_h, proj_w, float(fov_up), float(fov_down),
                                                       float(max_range), _ptr(yaw), _ptr(pitch), _ptr(pix), self._stream()),
                        "ovn_projection_angles")
@@ -432,7 +448,7 @@ class OvnEngine:
         """(o2 (n,24,24,128), o3 (n,22,22,256)) left in scratch by the last heads() call -- test hook."""
         o2 = torch.empty((n, 24, 24, 128), dtype=torch.float32, device=self.device)
         o3 = torch.empty((n, 22, 22, 256), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_debug_head_activations(self._h, n, _ptr(o2), _ptr(o3), self._stream()),
                        "ovn_debug_head_activations")
         return o2, o3
@@ -510,12 +526,12 @@ class OvnEngine:
         """{kind: (total_ms, launches)} measured with HIP events on the launch stream."""
         ms = (C.c_double * len(self.PROFILE_KINDS))()
         cnt = (C.c_int64 * len(self.PROFILE_KINDS))()
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_profile_end(self._h, ms, cnt), "ovn_profile_end")
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(self.PROFILE_KINDS)}
 
     def selftest(self) -> None:
-        with torch.cuda.device(self.device):
+        with self._dev():
             _lib.check(self.lib.ovn_selftest(self._h), "ovn_selftest")
 
     def workspace_bytes(self) -> int:
