@@ -286,11 +286,30 @@ __global__ __launch_bounds__(64 * NWV) void c3_dense_kernel(const float* __restr
   }
 }
 
+// The same finish as its own launch, for sweeps: there the device-scope release in front of the arrival counter (an L2 write-back per
+// workgroup on this multi-XCD part) costs more than a launch -- c3_dense 0.634 + 0.008 ms separate against 0.690 ms fused per 1024 pairs.
+__global__ __launch_bounds__(256) void dense_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bd, int n,
+                                                           float* __restrict__ overlap, float* __restrict__ logit) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const float* q = partial + (size_t)p * OVN_DENSE_PARTIALS;
+  float z = 0.f;
+#pragma unroll
+  for (int b = 0; b < NBAND; ++b) {
+    const float zb = (q[4 * b] + q[4 * b + 1]) + (q[4 * b + 2] + q[4 * b + 3]);   // the order of the fused finish
+    z = b == 0 ? zb : z + zb;
+  }
+  z += bd[0];
+  if (logit) logit[p] = z;
+  overlap[p] = 1.0f / (1.0f + expf(-z));
+}
+
 }  // namespace
 
 // o2 (n,24,24,128) fp32 -> Dense partial sums per (output-row band, half of the output channels, m-tile half) in `partial` (12 n) and,
-// with `overlap` given, logit / overlap of every pair (finished by the pair's last workgroup; `arrived`: n zeroed words that the kernel
-// leaves zeroed) [+ o3 (n,22,22,256) when not NULL].
+// with `overlap` given, logit / overlap of every pair -- for a handful of pairs finished by the pair's last workgroup inside the
+// kernel (`arrived`: n zeroed words that the kernel leaves zeroed), for sweeps by a small launch of its own; the same sums in the same
+// order either way [+ o3 (n,22,22,256) when not NULL].
 int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2max, int n, float* partial, float* o3,
                          unsigned* arrived, float* overlap, float* logit, hipStream_t stream) {
   OVN_REQUIRE(o2max != nullptr, OVN_ERR_ARG, "ovn_c3_dense_forward: the per-pair maxima of o2 are required");
@@ -302,12 +321,14 @@ int ovn_c3_dense_forward(const ovn_ctx* ctx, const float* o2, const unsigned* o2
     hipLaunchKernelGGL((c3_dense_kernel<ArithF16, 4, 2>), dim3(4 * NBAND * n), dim3(64 * 4), LDS_BYTES, stream, o2,
                        reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3, arrived,
                        ctx->bd, overlap, logit);
-  } else {
+  } else {         // sweeps: the finish as its own small launch (see dense_finish_kernel)
     rc = ovn_allow_dynamic_lds(reinterpret_cast<const void*>(c3_dense_kernel<ArithF16, NW, 1>), LDS_BYTES);
     if (rc) return rc;
     hipLaunchKernelGGL((c3_dense_kernel<ArithF16, NW, 1>), dim3(NBAND * n), dim3(64 * NW), LDS_BYTES, stream, o2,
-                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3, arrived,
-                       ctx->bd, overlap, logit);
+                       reinterpret_cast<const _Float16*>(ctx->c3.wp_h), ctx->c3.bias, ctx->wd, o2max, ctx->c3.sw_h, partial, o3,
+                       (unsigned*)nullptr, ctx->bd, (float*)nullptr, (float*)nullptr);
+    if (overlap != nullptr)
+      hipLaunchKernelGGL(dense_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partial, ctx->bd, n, overlap, logit);
   }
   OVN_HIP_CHECK(hipGetLastError());
   return OVN_OK;
