@@ -1045,6 +1045,12 @@ def main():
     for k, v in rl0.items():            # flop_per_launch, pairs_per_launch, delta_total_ms, note, ...
         rl.setdefault(k, v)
     out["roofline"] = rl
+    # next to `value` at the top level: what the same step does without the data-dependent part, and on the second weight set
+    if "dense_walk" in out:
+        out["value_dense_walk"] = out["dense_walk"]["value"]
+    if "trained_like" in out:
+        out["value_trained_like"] = out["trained_like"]["compacted"]["value"]
+        out["value_trained_like_dense_walk"] = out["trained_like"]["dense_walk"]["value"]
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(C, P)
         if not args.no_extras:
