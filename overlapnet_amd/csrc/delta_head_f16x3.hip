@@ -487,8 +487,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 }
 
 // Per pair: value range -> shift and scales; both volumes packed ONCE into the word streams the c_conv1 kernel DMAs into LDS
-//   pl[pair][s(4)][i(360)][g(4)][8]       L words, channel slice major: lane (row, g) of slice s reads 32 contiguous bytes
-//   pr[pair][jb(24)][s(4)][dj(15)][g(4)][8] R words in the order of one pass's LDS image (two column groups = 15,360 B contiguous)
+//   pl[pair][c(128)][i(360)]              L words, CHANNEL-major: the contraction kernel fetches 32 rows of the channels its walk names
+//   pr[pair][jb(24)][s(4)][dj(15)][g(4)][8] R words in the order of the K walk: a chunk of 3 taps of a column group is 384 contiguous bytes
 // and the linear terms lin[pair] = {TT + b2 [24][128], AA [24][128]} (fp16 MFMA on the T image in LDS / plain FMAs).
 // scales[2 pair] = {sa, -2 s1r / (sa sw1), s1r, 1 / (s1r sw2)}; s1r = scale of -2 M, bounded by 2 span max_o sum |W1[., o]|.
 // One workgroup per pair and one workgroup per CU (129 KB of LDS), so nothing hides a memory round trip: every phase issues ALL of
