@@ -96,6 +96,23 @@ class FeatureVolumeCache(object):
         self._engine.delta_cache(self._fv[slot:slot + k], out=self._dc[slot:slot + k])
     self._n = max(self._n, slot + k)
 
+  def put_slots_device(self, slots, fv: torch.Tensor) -> None:
+    """Write k volumes at k arbitrary (distinct) slots: ONE batched spectrum / Delta-row computation on the contiguous input and one
+    indexed copy per pool -- the sharded cache rebuilt from a list, whose slots are not consecutive (distributed.frame_slot)."""
+    slots = np.asarray(slots, dtype=np.int64).reshape(-1)
+    k = fv.shape[0]
+    if k == 0:
+      return
+    if len(slots) != k or len(np.unique(slots)) != k or slots.min() < 0:
+      raise ValueError('put_slots_device: %d volumes for slots %s' % (k, slots[:8]))
+    self._grow(max(self._n, int(slots.max()) + 1))
+    idx = torch.from_numpy(slots).to(fv.device)
+    self._fv.index_copy_(0, idx, fv)
+    self._spec.index_copy_(0, idx, self._engine.spectrum(fv))
+    if self._with_dc:
+      self._dc.index_copy_(0, idx, self._engine.delta_cache(fv))
+    self._n = max(self._n, int(slots.max()) + 1)
+
   def extend_device(self, fv: torch.Tensor, spec: Optional[torch.Tensor] = None, dc: Optional[torch.Tensor] = None) -> None:
     """Append k volumes (see put_device)."""
     self.put_device(self._n, fv, spec=spec, dc=dc)
@@ -321,14 +338,13 @@ class Infer():
       ids = np.arange(vols.shape[0])
       mine = ids[D.frame_owner(ids, self._world) == self._rank]
       slots = D.frame_slot(mine, self._world)
-      order = np.argsort(slots, kind='stable')         # increasing slot order
-      mine, slots = mine[order], slots[order]
-      # ONE host-to-device copy of everything this rank owns, then one put_device (copy + batched spectrum / Delta rows) per RUN of
-      # consecutive slots: a rank's slots are contiguous except where a frame of the last, incomplete round is still missing
-      dev_vols = torch.from_numpy(np.ascontiguousarray(vols[mine])).to(self.engine.device)
-      starts = np.concatenate([[0], np.nonzero(np.diff(slots) != 1)[0] + 1, [len(slots)]])
-      for a, b in zip(starts[:-1], starts[1:]):
-        cache.put_device(int(slots[a]), dev_vols[a:b])
+      # ONE host-to-device copy of everything this rank owns, ONE batched spectrum and Delta-row computation, one indexed copy per
+      # pool (under the skewed block-cyclic ownership a rank's slots are hardly ever consecutive: per-frame writes were one copy and
+      # two launches per frame -- ADVICE r5)
+      if len(mine):
+        dev_vols = torch.from_numpy(np.ascontiguousarray(vols[mine])).to(self.engine.device)
+        for a in range(0, len(mine), 4096):      # (chunks bound the transient spectra / Delta rows)
+          cache.put_slots_device(slots[a:a + 4096], dev_vols[a:a + 4096])
     elif vols.shape[0]:
       cache.extend_device(torch.from_numpy(vols).to(self.engine.device))
     self._feature_volumes = cache

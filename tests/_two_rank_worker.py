@@ -128,6 +128,17 @@ def infer_api(work):
     if rank == 0:
         b2, b3, b4 = ref.infer_multiple(2, [0, 1]), ref.infer_multiple(3, [0, 1, 2]), ref.infer_multiple(4, [0, 1, 2, 3])
         report["retry_ok"] = bool(all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in ((a2, b2), (a3, b3), (a4, b4))))
+    # the cache rebuilt from a LIST of volumes in sharded mode (the reference's `infer.feature_volumes = [...]`): every rank keeps the
+    # frames it owns at their slots (one batched upload), and the next sweep over all of them equals the unsharded object's
+    vols = [None]
+    if rank == 0:
+        vols = [np.asarray(ref.feature_volumes)]          # frames 0 .. 4 of the unsharded cache: (5, 1, 360, 128)
+    dist.broadcast_object_list(vols, src=0)
+    sh.feature_volumes = list(vols[0])
+    a5 = sh.infer_multiple(5, [0, 1, 2, 3, 4])
+    if rank == 0:
+        b5 = ref.infer_multiple(5, [0, 1, 2, 3, 4])
+        report["list_reset_ok"] = bool(np.array_equal(a5[0], b5[0]) and np.array_equal(a5[1], b5[1]))
     sh.close()
     if ref is not None:
         ref.close()

@@ -79,7 +79,7 @@ def test_sharded_infer_equals_the_unsharded_object(tmp_path, fixture_npz):
     f = r["one_rank_failure"]
     assert len(f[0]) == 3 and all("rank(s) [1]" in m for m in f[0]) and all("simulated" in m for m in f[1]), f      # rank 0 / rank 1: both raise, all three calls
     assert r["retry_ok"] is True      # the failed frame did not count as fed: fed again after the repair, then referenced by the next frame
-    assert r["order_error"] is True and r["reset_ok"] is True
+    assert r["order_error"] is True and r["reset_ok"] is True and r["list_reset_ok"] is True
     assert len(r["best"]) == frames // 5 and any(b[0] is not None for b in r["best"])
 
 
